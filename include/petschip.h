@@ -1,0 +1,163 @@
+/*
+ * petschip.h -- C ABI of libpetschip.so: the MI355X (gfx950) kernels behind PETSc's AIJ/Vec/Jacobi
+ * ops tables.  Plain C, plain pointers and sizes; no PETSc, torch or C++ types cross this boundary.
+ *
+ * This is the layer a PETSc-side glue file binds: each MATSEQAIJHIP/MATMPIAIJHIP/VECSEQHIP/VECMPIHIP
+ * ops-table entry unpacks the PETSc structs and calls exactly one function below (INTEGRATION.md shows
+ * the glue).  Each declaration cites the reference routine (file:line under the PETSc 3.6.1 tree) whose
+ * ops-table slot it fills and whose result it reproduces.
+ *
+ * Conventions
+ *   - PetscInt = int32_t, PetscScalar = PetscReal = double.
+ *   - Return value: 0 on success, otherwise a PetscErrorCode value (include/petscerror.h:24-68):
+ *       PHIP_ERR_MEM 55, PHIP_ERR_SUP 56, PHIP_ERR_ARG_SIZ 60, PHIP_ERR_ARG_OUTOFRANGE 63,
+ *       PHIP_ERR_ARG_WRONGSTATE 73, PHIP_ERR_LIB 76 (any HIP / RCCL failure), PHIP_ERR_ARG_NULL 85.
+ *     phip_last_error() returns the text of the last failure on the calling thread.
+ *   - "d_" pointers are device pointers obtained from phip_malloc (or any hipMalloc'd memory);
+ *     "h_" pointers are host pointers.  The library owns what it allocates; callers own the rest.
+ *   - One phip_ctx per process and GPU.  All work of a context is issued on its compute stream, in
+ *     call order; calls that return a host scalar (dot/norm/mdot) synchronise that stream, everything
+ *     else is asynchronous.  Contexts are not thread-safe (PETSc 3.6 objects are not either).
+ *   - There is no CPU fallback: without a usable GPU phip_init fails with PHIP_ERR_LIB.
+ */
+#ifndef PETSCHIP_H
+#define PETSCHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHIP_ERR_MEM            55
+#define PHIP_ERR_SUP            56
+#define PHIP_ERR_ARG_SIZ        60
+#define PHIP_ERR_ARG_OUTOFRANGE 63
+#define PHIP_ERR_ARG_WRONGSTATE 73
+#define PHIP_ERR_LIB            76
+#define PHIP_ERR_ARG_NULL       85
+
+/* NormType, include/petscvec.h:155 */
+#define PHIP_NORM_1         0
+#define PHIP_NORM_2         1
+#define PHIP_NORM_FROBENIUS 2
+#define PHIP_NORM_INFINITY  3
+#define PHIP_NORM_1_AND_2   4
+
+#define PHIP_MAX_MVEC 128 /* VecMDot_MPI's stack bound, src/vec/vec/impls/mpi/pvec2.c:13 */
+
+typedef struct phip_ctx_s  *phip_ctx;
+typedef struct phip_mat_s  *phip_mat;
+typedef struct phip_comm_s *phip_comm;
+typedef struct phip_halo_s *phip_halo;
+
+/* ---- context / memory -------------------------------------------------------------------------
+ * Replaces the CUSP precedent's implicit global state (VecCUSPAllocateCheck / CopyToGPU / CopyFromGPU,
+ * src/vec/vec/impls/seq/seqcusp/veccusp.cu:55-180) with an explicit per-process context. */
+int         phip_init(int device, phip_ctx *ctx);
+int         phip_finalize(phip_ctx ctx);
+const char *phip_last_error(void);
+int         phip_device_info(phip_ctx ctx, int *device, int *cu_count, size_t *hbm_bytes, char *name, int name_len);
+int         phip_malloc(phip_ctx ctx, size_t bytes, void **d_ptr);
+int         phip_free(phip_ctx ctx, void *d_ptr);
+int         phip_memcpy_h2d(phip_ctx ctx, void *d_dst, const void *h_src, size_t bytes); /* VecCUSPCopyToGPU   veccusp.cu:90  */
+int         phip_memcpy_d2h(phip_ctx ctx, void *h_dst, const void *d_src, size_t bytes); /* VecCUSPCopyFromGPU veccusp.cu:152 (synchronises) */
+int         phip_memcpy_d2d(phip_ctx ctx, void *d_dst, const void *d_src, size_t bytes);
+int         phip_sync(phip_ctx ctx);                                                     /* WaitForGPU, cuspvecimpl.h:66 */
+void       *phip_stream(phip_ctx ctx);          /* the hipStream_t all work is issued on */
+/* hipEvent timing on the context's stream (PetscLogEventBegin/End's role for device work, include/petsclog.h:284-295):
+ * record two events around a region, then phip_event_elapsed_ms synchronises on the second and returns the device time. */
+int         phip_event_create(phip_ctx ctx, void **event);
+int         phip_event_record(phip_ctx ctx, void *event);
+int         phip_event_elapsed_ms(phip_ctx ctx, void *start, void *stop, float *ms);
+int         phip_event_destroy(phip_ctx ctx, void *event);
+
+/* ---- device CSR matrix (Mat_SeqAIJ on the GPU) --------------------------------------------------
+ * phip_mat_create uploads a host CSR exactly as MatAssemblyEnd_SeqAIJ leaves it (src/mat/impls/aij/seq/aij.c:
+ * 968-1024: i[m+1], j[nz] sorted per row, a[nz]) and builds the row-block plan the SpMV kernel runs on.
+ * Precedent slot: MatCUSPCopyToGPU, src/mat/impls/aij/seq/seqcusp/aijcusp.cu:110-208.
+ * use_cprow/cprow_*: the Mat_CompressedRow of MatCheckCompressedRow (src/mat/utils/compressedrow.c:32-74);
+ * pass use_cprow = 0 and NULLs when the host matrix does not use it. */
+int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t *h_i, const int32_t *h_j, const double *h_a,
+                    int use_cprow, int32_t cprow_nrows, const int32_t *h_cprow_i, const int32_t *h_cprow_rindex,
+                    phip_mat *A);
+/* same pattern, new values (MatAssemblyEnd with unchanged nonzerostate; aijcusp.cu:451-462 re-uploads everything) */
+int phip_mat_update_values(phip_mat A, const double *h_a);
+int phip_mat_destroy(phip_mat A);
+/* y = A x.  MatMult_SeqAIJ, aij.c:1272-1327 (cprow branch :1295-1308 zero-fills y). d_x has n entries, d_y m. */
+int phip_mat_mult(phip_mat A, const double *d_x, double *d_y);
+/* z = y + A x.  MatMultAdd_SeqAIJ, aij.c:1440-1499; d_z may alias d_y (mpiaij.c:996 calls it that way). */
+int phip_mat_multadd(phip_mat A, const double *d_x, const double *d_y, double *d_z);
+/* v[i] = a[k] where j[k]==i, else 0.  MatGetDiagonal_SeqAIJ, aij.c:1169-1202. */
+int phip_mat_getdiagonal(phip_mat A, double *d_v);
+/* Row-block plan introspection (tests): number of blocks, nnz capacity per block, threads per row used. */
+int phip_mat_plan_info(phip_mat A, int32_t *nblocks, int32_t *block_nnz_cap, int32_t *threads_per_row, int64_t *nnz);
+int phip_mat_plan_get(phip_mat A, int32_t *h_block_row /* nblocks+1 */);
+/* tuning: threads_per_row (0 = auto), 1,2,4,...,64 */
+int phip_mat_set_threads_per_row(phip_mat A, int32_t tpr);
+
+/* ---- vector kernels (the _VecOps slots, include/petsc/private/vecimpl.h:20-96) --------------------
+ * n = local length.  Results of reductions are written to host memory and are valid on return. */
+int phip_vec_dot(phip_ctx ctx, int32_t n, const double *d_x, const double *d_y, double *h_z);        /* VecDot_Seq/VecTDot_Seq bvec1.c:12-51 */
+int phip_vec_norm(phip_ctx ctx, int32_t n, const double *d_x, int type, double *h_z);                /* VecNorm_Seq bvec2.c:233-271 (h_z[2] for 1_AND_2) */
+int phip_vec_mdot(phip_ctx ctx, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *h_z); /* VecMDot_Seq dvec2.c:98-294 */
+int phip_vec_maxpy(phip_ctx ctx, int32_t n, double *d_x, int32_t nv, const double *h_alpha, const double *const *h_dy); /* VecMAXPY_Seq dvec2.c:570-638 */
+int phip_vec_axpy(phip_ctx ctx, int32_t n, double *d_y, double alpha, const double *d_x);            /* VecAXPY_Seq bvec1.c:76-95 */
+int phip_vec_aypx(phip_ctx ctx, int32_t n, double *d_y, double alpha, const double *d_x);            /* VecAYPX_Seq dvec2.c:644-686 */
+int phip_vec_waxpy(phip_ctx ctx, int32_t n, double *d_w, double alpha, const double *d_x, const double *d_y); /* VecWAXPY_Seq dvec2.c:697-730 */
+int phip_vec_axpby(phip_ctx ctx, int32_t n, double *d_y, double alpha, double beta, const double *d_x);       /* VecAXPBY_Seq bvec1.c:99-133 */
+int phip_vec_axpbypcz(phip_ctx ctx, int32_t n, double *d_z, double alpha, double beta, double gamma, const double *d_x, const double *d_y); /* bvec1.c:137-165 */
+int phip_vec_pointwise_mult(phip_ctx ctx, int32_t n, double *d_w, const double *d_x, const double *d_y);      /* VecPointwiseMult_Seq bvec2.c:84-110 */
+int phip_vec_pointwise_divide(phip_ctx ctx, int32_t n, double *d_w, const double *d_x, const double *d_y);    /* VecPointwiseDivide_Seq bvec2.c:114-132 */
+int phip_vec_scale(phip_ctx ctx, int32_t n, double *d_x, double alpha);                              /* VecScale_Seq bvec1.c:55-72 */
+int phip_vec_copy(phip_ctx ctx, int32_t n, const double *d_x, double *d_y);                          /* VecCopy_Seq bvec2.c:192-207 */
+int phip_vec_set(phip_ctx ctx, int32_t n, double *d_x, double alpha);                                /* VecSet_Seq dvec2.c:551-566 */
+int phip_vec_swap(phip_ctx ctx, int32_t n, double *d_x, double *d_y);                                /* VecSwap_Seq bvec2.c:211-227 */
+int phip_vec_reciprocal(phip_ctx ctx, int32_t n, double *d_x);                                       /* VecReciprocal_Default vinv.c:1213-1227 */
+/* PCSetUp_Jacobi's host loop (src/ksp/pc/impls/jacobi/jacobi.c:182-195) on the device: d = 1/d (0 stays 0), optional |d|, 0 -> 1.0.
+ * h_zeroflag (may be NULL) receives 1 when a zero was replaced.  sqrt_variant selects :196-214 (1/sqrt|d|). */
+int phip_jacobi_setup(phip_ctx ctx, int32_t n, double *d_diag, int useabs, int sqrt_variant, int *h_zeroflag);
+
+/* Local halves of the distributed reductions (VecDot_MPI pbvec.c:9-19, VecNorm_MPI pvec2.c:49-85, VecMDot_MPI pvec2.c:10-25):
+ * the local kernel leaves its result in device memory (d_out, nv doubles) so that phip_comm_allreduce can combine it without
+ * a host round trip; phip_read_scalars then brings the final values to the host.
+ * kind: 0 dot(x,y[0]) / mdot(x,y[0..nv-1]);  1 sum x_i^2 (nv=1);  2 sum |x_i| ;  3 max |x_i| (NaN propagates);  4 {sum|x|, sum x^2} */
+int phip_vec_reduce_local(phip_ctx ctx, int kind, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *d_out);
+int phip_read_scalars(phip_ctx ctx, const double *d_src, int32_t n, double *h_dst);
+
+/* ---- communicator: one rank per GPU, RCCL over xGMI ---------------------------------------------
+ * Replaces MPI_Allreduce in the MPI Vec types and the MPI persistent send/recv of VecScatterBegin/End
+ * (src/vec/vec/utils/vpscat.h:14-196).  backend "rccl": id128 is the 128-byte ncclUniqueId made by rank 0 with
+ * phip_comm_unique_id and handed to every rank by the embedding application (bench.py uses torch.distributed).
+ * backend "self": size-1 communicator, no library needed.  backend "threads": ranks are host threads of ONE process
+ * sharing one GPU (test harness for the distributed code path on a single-GPU box; id128 then holds a group key). */
+int phip_comm_unique_id(void *id128);
+int phip_comm_create(phip_ctx ctx, const char *backend, const void *id128, int nranks, int rank, phip_comm *comm);
+int phip_comm_destroy(phip_comm comm);
+int phip_comm_rank_size(phip_comm comm, int *rank, int *size);
+/* in-place all-reduce of n doubles in device memory, op 0 = SUM, 1 = MAX; stream-ordered on the context's stream */
+int phip_comm_allreduce(phip_comm comm, double *d_buf, int32_t n, int op);
+/* host-side collectives used at set-up (the PetscGatherNumberOfMessages/MessageLengths + Isend/Irecv handshake of
+ * VecScatterCreate_PtoS, vpscat.c:2346-2392): all-gather of fixed-size records and variable all-to-all of int32 lists */
+int phip_comm_allgather_host(phip_comm comm, const void *h_send, void *h_recv, size_t bytes_per_rank);
+int phip_comm_alltoallv_i32(phip_comm comm, const int32_t *h_send, const int32_t *send_counts, int32_t *h_recv, const int32_t *recv_counts);
+int phip_comm_barrier(phip_comm comm);
+
+/* ---- ghost exchange (the VecScatter of MatMult_MPIAIJ) -------------------------------------------
+ * Plan = VecScatter_MPI_General "to" and "from" (include/petsc/private/vecimpl.h:245-273) as built by
+ * VecScatterCreate_PtoS (vpscat.c:2297-2495): send side to_procs ascending / to_starts / to_indices (local offsets),
+ * receive side from_procs ascending / from_starts, landing contiguously in lvec (from->contiq, vpscat.c:2524-2532).
+ * begin: pack kernel (Pack_1, vpscat.c:494-498) + grouped send/recv on the communication stream (VecScatterBegin_1 vpscat.h:14-126);
+ * end:   the compute stream waits for the exchange (VecScatterEnd_1 vpscat.h:132-196).  The diagonal-block SpMV issued between
+ * begin and end overlaps the exchange exactly as mpiaij.c:990-996 intends. */
+int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_procs, const int32_t *to_starts, const int32_t *to_indices,
+                     int32_t from_n, const int32_t *from_procs, const int32_t *from_starts, phip_halo *halo);
+int phip_halo_destroy(phip_halo halo);
+int phip_halo_begin(phip_halo halo, const double *d_x_local, double *d_lvec);
+int phip_halo_end(phip_halo halo);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PETSCHIP_H */

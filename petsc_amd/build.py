@@ -1,0 +1,52 @@
+"""Build the HIP shared libraries in-tree (gfx950 only).  hipcc cross-compiles without a GPU."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+KERNEL_SRCS = ["phip_runtime.hip", "phip_spmv.hip", "phip_vec.hip", "phip_comm.hip"]
+HOST_SRCS = ["host/petsc_host.cpp"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+          "-I/opt/rocm/include", "-I" + os.path.join(os.path.dirname(HERE), "include")]
+
+
+def _stale(out, srcs):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    deps = list(srcs)
+    for root, _, files in os.walk(CSRC):
+        deps += [os.path.join(root, f) for f in files if f.endswith((".h", ".hpp"))]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "petschip.h"))
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "petschip_host.h"))
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    outs = []
+    kout = os.path.join(LIBDIR, "libpetschip.so")
+    ksrcs = [os.path.join(CSRC, s) for s in KERNEL_SRCS]
+    if force or _stale(kout, ksrcs):
+        cmd = [HIPCC, "--offload-arch=gfx950", *COMMON, *ksrcs, "-o", kout, "-ldl", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    outs.append(kout)
+    hsrcs = [os.path.join(CSRC, s) for s in HOST_SRCS]
+    if all(os.path.exists(s) for s in hsrcs):
+        hout = os.path.join(LIBDIR, "libpetschip_host.so")
+        if force or _stale(hout, hsrcs) or os.path.getmtime(kout) > os.path.getmtime(hout):
+            cmd = [HIPCC, *COMMON, "-x", "c++", *hsrcs, "-o", hout, "-L" + LIBDIR, "-lpetschip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        outs.append(hout)
+    return outs
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

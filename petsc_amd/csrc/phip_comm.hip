@@ -1,0 +1,408 @@
+// Communicator and ghost exchange of libpetschip (see include/petschip.h).
+//
+// backend "rccl"    one process per GPU; librccl is dlopen'ed on first use (so single-GPU users never need it).
+//                   Reductions are ncclAllReduce on the compute stream; the ghost exchange is one grouped
+//                   ncclSend/ncclRecv per neighbour on the communication stream, received straight into lvec
+//                   (the receive side of MatSetUpMultiply's scatter is contiguous, vpscat.c:2524-2532).
+//                   xGMI is point to point, so neighbour exchanges use one link per peer and never a ring.
+// backend "self"    size 1.
+// backend "threads" the ranks are host threads of one process that share one GPU; collectives rendezvous through a
+//                   process-wide table.  It exists so that the distributed code path (plan handshake, pack kernel, lvec
+//                   offsets, overlap ordering) can be exercised on a single-GPU box; it is not a performance path.
+#include "phip_internal.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <stdlib.h>
+#include <condition_variable>
+#include <map>
+#include <mutex>
+#include <vector>
+
+/* ---- RCCL entry points (resolved at run time) --------------------------------------------------- */
+struct RcclApi {
+  void *handle;
+  decltype(&ncclGetUniqueId)   GetUniqueId;
+  decltype(&ncclCommInitRank)  CommInitRank;
+  decltype(&ncclCommDestroy)   CommDestroy;
+  decltype(&ncclAllReduce)     AllReduce;
+  decltype(&ncclAllGather)     AllGather;
+  decltype(&ncclSend)          Send;
+  decltype(&ncclRecv)          Recv;
+  decltype(&ncclGroupStart)    GroupStart;
+  decltype(&ncclGroupEnd)      GroupEnd;
+  decltype(&ncclGetErrorString) GetErrorString;
+};
+static RcclApi    g_rccl;
+static std::mutex g_rccl_mutex;
+
+static int rccl_load(void)
+{
+  std::lock_guard<std::mutex> lk(g_rccl_mutex);
+  if (g_rccl.handle) return 0;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void       *h = NULL;
+  for (size_t i = 0; i < sizeof(names) / sizeof(names[0]) && !h; i++) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+  PHIP_REQUIRE(h, PHIP_ERR_LIB, "cannot load librccl: %s", dlerror());
+#define RESOLVE(field, sym)                                                                   \
+  g_rccl.field = (decltype(g_rccl.field))dlsym(h, sym);                                       \
+  PHIP_REQUIRE(g_rccl.field, PHIP_ERR_LIB, "librccl lacks symbol %s", sym)
+  RESOLVE(GetUniqueId, "ncclGetUniqueId");
+  RESOLVE(CommInitRank, "ncclCommInitRank");
+  RESOLVE(CommDestroy, "ncclCommDestroy");
+  RESOLVE(AllReduce, "ncclAllReduce");
+  RESOLVE(AllGather, "ncclAllGather");
+  RESOLVE(Send, "ncclSend");
+  RESOLVE(Recv, "ncclRecv");
+  RESOLVE(GroupStart, "ncclGroupStart");
+  RESOLVE(GroupEnd, "ncclGroupEnd");
+  RESOLVE(GetErrorString, "ncclGetErrorString");
+#undef RESOLVE
+  g_rccl.handle = h;
+  return 0;
+}
+
+#define PHIP_CHECK_NCCL(call)                                                                          \
+  do {                                                                                                 \
+    ncclResult_t _r = (call);                                                                          \
+    if (_r != ncclSuccess) {                                                                           \
+      phip_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, g_rccl.GetErrorString(_r));    \
+      return PHIP_ERR_LIB;                                                                             \
+    }                                                                                                  \
+  } while (0)
+
+/* ---- "threads" backend rendezvous ---------------------------------------------------------------- */
+struct ThreadGroup {
+  int                     n;
+  std::mutex              m;
+  std::condition_variable cv;
+  int                     waiting = 0;
+  long                    generation = 0;
+  std::vector<const void *> slot_a, slot_b;
+  int                     refs = 0;
+  void barrier()
+  {
+    std::unique_lock<std::mutex> lk(m);
+    const long gen = generation;
+    if (++waiting == n) { waiting = 0; generation++; cv.notify_all(); }
+    else cv.wait(lk, [&] { return gen != generation; });
+  }
+};
+static std::map<uint64_t, ThreadGroup *> g_groups;
+static std::mutex                        g_groups_mutex;
+
+enum { BACKEND_SELF = 0, BACKEND_RCCL = 1, BACKEND_THREADS = 2 };
+
+struct phip_comm_s {
+  phip_ctx     ctx;
+  int          backend, rank, size;
+  ncclComm_t   nccl;
+  ThreadGroup *tg;
+  uint64_t     tg_key;
+};
+
+struct phip_halo_s {
+  phip_comm comm;
+  int32_t   to_n, from_n, nsend, nrecv;
+  std::vector<int32_t> to_procs, to_starts, from_procs, from_starts;
+  int32_t  *d_to_indices;
+  double   *d_sendbuf;
+  hipEvent_t ev_packed, ev_done;
+  const double *cur_lvec;
+  double   *lvec;
+};
+
+extern "C" int phip_comm_unique_id(void *id128)
+{
+  PHIP_REQUIRE(id128, PHIP_ERR_ARG_NULL, "phip_comm_unique_id: null buffer");
+  int rc = rccl_load();
+  if (rc) return rc;
+  ncclUniqueId id;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  PHIP_CHECK_NCCL(g_rccl.GetUniqueId(&id));
+  memcpy(id128, &id, 128);
+  return 0;
+}
+
+extern "C" int phip_comm_create(phip_ctx ctx, const char *backend, const void *id128, int nranks, int rank, phip_comm *out)
+{
+  PHIP_REQUIRE(ctx && backend && out, PHIP_ERR_ARG_NULL, "phip_comm_create: null argument");
+  PHIP_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: rank %d of %d", rank, nranks);
+  phip_comm c = new phip_comm_s();
+  c->ctx = ctx; c->rank = rank; c->size = nranks; c->nccl = NULL; c->tg = NULL; c->tg_key = 0;
+  if (!strcmp(backend, "self")) {
+    PHIP_REQUIRE(nranks == 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: backend self needs nranks 1");
+    c->backend = BACKEND_SELF;
+  } else if (!strcmp(backend, "rccl")) {
+    PHIP_REQUIRE(id128, PHIP_ERR_ARG_NULL, "phip_comm_create: rccl backend needs the unique id");
+    int rc = rccl_load();
+    if (rc) { delete c; return rc; }
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    PHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    PHIP_CHECK_NCCL(g_rccl.CommInitRank(&c->nccl, nranks, id, rank));
+    c->backend = BACKEND_RCCL;
+  } else if (!strcmp(backend, "threads")) {
+    PHIP_REQUIRE(id128, PHIP_ERR_ARG_NULL, "phip_comm_create: threads backend needs a group key");
+    memcpy(&c->tg_key, id128, sizeof(uint64_t));
+    {
+      std::lock_guard<std::mutex> lk(g_groups_mutex);
+      ThreadGroup *&g = g_groups[c->tg_key];
+      if (!g) { g = new ThreadGroup(); g->n = nranks; g->slot_a.resize((size_t)nranks); g->slot_b.resize((size_t)nranks); }
+      PHIP_REQUIRE(g->n == nranks, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: thread group size mismatch");
+      g->refs++;
+      c->tg = g;
+    }
+    c->backend = BACKEND_THREADS;
+  } else {
+    delete c;
+    PHIP_REQUIRE(0, PHIP_ERR_SUP, "phip_comm_create: unknown backend '%s'", backend);
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int phip_comm_destroy(phip_comm c)
+{
+  if (!c) return 0;
+  if (c->backend == BACKEND_RCCL && c->nccl) {
+    hipSetDevice(c->ctx->device);
+    hipStreamSynchronize(c->ctx->stream);
+    hipStreamSynchronize(c->ctx->comm_stream);
+    g_rccl.CommDestroy(c->nccl);
+  }
+  if (c->backend == BACKEND_THREADS) {
+    std::lock_guard<std::mutex> lk(g_groups_mutex);
+    if (--c->tg->refs == 0) { g_groups.erase(c->tg_key); delete c->tg; }
+  }
+  delete c;
+  return 0;
+}
+
+extern "C" int phip_comm_rank_size(phip_comm c, int *rank, int *size)
+{
+  PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_comm_rank_size: null communicator");
+  if (rank) *rank = c->rank;
+  if (size) *size = c->size;
+  return 0;
+}
+
+extern "C" int phip_comm_barrier(phip_comm c)
+{
+  PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_comm_barrier: null communicator");
+  if (c->backend == BACKEND_THREADS) c->tg->barrier();
+  else if (c->backend == BACKEND_RCCL) {
+    int32_t one = 1;
+    std::vector<int32_t> all((size_t)c->size);
+    return phip_comm_allgather_host(c, &one, all.data(), sizeof(int32_t));
+  }
+  return 0;
+}
+
+extern "C" int phip_comm_allreduce(phip_comm c, double *d_buf, int32_t n, int op)
+{
+  PHIP_REQUIRE(c && (d_buf || !n), PHIP_ERR_ARG_NULL, "phip_comm_allreduce: null argument");
+  PHIP_REQUIRE(n >= 0 && n <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_allreduce: n=%d", n);
+  PHIP_REQUIRE(op == 0 || op == 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_allreduce: op %d", op);
+  if (c->size == 1 || n == 0) return 0;
+  if (c->backend == BACKEND_RCCL) {
+    PHIP_CHECK_NCCL(g_rccl.AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->nccl, c->ctx->stream));
+    return 0;
+  }
+  /* threads: gather every rank's values on the host, combine in rank order, write back */
+  ThreadGroup *g = c->tg;
+  PHIP_CHECK_HIP(hipStreamSynchronize(c->ctx->stream));
+  g->slot_a[(size_t)c->rank] = d_buf;
+  g->barrier();
+  std::vector<double> acc((size_t)n), tmp((size_t)n);
+  for (int p = 0; p < c->size; p++) {
+    PHIP_CHECK_HIP(hipMemcpy(tmp.data(), g->slot_a[(size_t)p], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+      if (p == 0) acc[(size_t)i] = tmp[(size_t)i];
+      else if (op == 0) acc[(size_t)i] += tmp[(size_t)i];
+      else acc[(size_t)i] = (tmp[(size_t)i] != tmp[(size_t)i] || tmp[(size_t)i] > acc[(size_t)i]) ? tmp[(size_t)i] : acc[(size_t)i];
+    }
+  }
+  g->barrier(); /* everyone has read before anyone overwrites */
+  PHIP_CHECK_HIP(hipMemcpy(d_buf, acc.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int phip_comm_allgather_host(phip_comm c, const void *h_send, void *h_recv, size_t bytes)
+{
+  PHIP_REQUIRE(c && h_send && h_recv, PHIP_ERR_ARG_NULL, "phip_comm_allgather_host: null argument");
+  if (c->backend == BACKEND_SELF) { memcpy(h_recv, h_send, bytes); return 0; }
+  if (c->backend == BACKEND_THREADS) {
+    ThreadGroup *g = c->tg;
+    g->slot_a[(size_t)c->rank] = h_send;
+    g->barrier();
+    for (int p = 0; p < c->size; p++) memcpy((char *)h_recv + (size_t)p * bytes, g->slot_a[(size_t)p], bytes);
+    g->barrier();
+    return 0;
+  }
+  void *d_s = NULL, *d_r = NULL;
+  PHIP_CHECK_HIP(hipSetDevice(c->ctx->device));
+  PHIP_CHECK_HIP(hipMalloc(&d_s, bytes + 16));
+  PHIP_CHECK_HIP(hipMalloc(&d_r, bytes * (size_t)c->size + 16));
+  PHIP_CHECK_HIP(hipMemcpyAsync(d_s, h_send, bytes, hipMemcpyHostToDevice, c->ctx->stream));
+  PHIP_CHECK_NCCL(g_rccl.AllGather(d_s, d_r, bytes, ncclInt8, c->nccl, c->ctx->stream));
+  PHIP_CHECK_HIP(hipMemcpyAsync(h_recv, d_r, bytes * (size_t)c->size, hipMemcpyDeviceToHost, c->ctx->stream));
+  PHIP_CHECK_HIP(hipStreamSynchronize(c->ctx->stream));
+  PHIP_CHECK_HIP(hipFree(d_s));
+  PHIP_CHECK_HIP(hipFree(d_r));
+  return 0;
+}
+
+extern "C" int phip_comm_alltoallv_i32(phip_comm c, const int32_t *h_send, const int32_t *send_counts, int32_t *h_recv, const int32_t *recv_counts)
+{
+  PHIP_REQUIRE(c && send_counts && recv_counts, PHIP_ERR_ARG_NULL, "phip_comm_alltoallv_i32: null argument");
+  std::vector<size_t> so((size_t)c->size + 1, 0), ro((size_t)c->size + 1, 0);
+  for (int p = 0; p < c->size; p++) { so[(size_t)p + 1] = so[(size_t)p] + (size_t)send_counts[p]; ro[(size_t)p + 1] = ro[(size_t)p] + (size_t)recv_counts[p]; }
+  if (c->backend == BACKEND_SELF) {
+    PHIP_REQUIRE(send_counts[0] == recv_counts[0], PHIP_ERR_ARG_SIZ, "phip_comm_alltoallv_i32: self counts differ");
+    if (send_counts[0]) memcpy(h_recv, h_send, sizeof(int32_t) * (size_t)send_counts[0]);
+    return 0;
+  }
+  if (c->backend == BACKEND_THREADS) {
+    ThreadGroup *g = c->tg;
+    g->slot_a[(size_t)c->rank] = h_send;
+    g->slot_b[(size_t)c->rank] = send_counts;
+    g->barrier();
+    for (int p = 0; p < c->size; p++) {
+      const int32_t *pc = (const int32_t *)g->slot_b[(size_t)p];
+      size_t         off = 0;
+      for (int q = 0; q < c->rank; q++) off += (size_t)pc[q];
+      PHIP_REQUIRE(pc[c->rank] == recv_counts[p], PHIP_ERR_ARG_SIZ, "phip_comm_alltoallv_i32: rank %d sends %d to %d, which expects %d", p, pc[c->rank], c->rank, recv_counts[p]);
+      if (recv_counts[p]) memcpy(h_recv + ro[(size_t)p], (const int32_t *)g->slot_a[(size_t)p] + off, sizeof(int32_t) * (size_t)recv_counts[p]);
+    }
+    g->barrier();
+    return 0;
+  }
+  int32_t *d_s = NULL, *d_r = NULL;
+  PHIP_CHECK_HIP(hipSetDevice(c->ctx->device));
+  PHIP_CHECK_HIP(hipMalloc((void **)&d_s, sizeof(int32_t) * (so[(size_t)c->size] + 4)));
+  PHIP_CHECK_HIP(hipMalloc((void **)&d_r, sizeof(int32_t) * (ro[(size_t)c->size] + 4)));
+  if (so[(size_t)c->size]) PHIP_CHECK_HIP(hipMemcpyAsync(d_s, h_send, sizeof(int32_t) * so[(size_t)c->size], hipMemcpyHostToDevice, c->ctx->stream));
+  PHIP_CHECK_NCCL(g_rccl.GroupStart());
+  for (int p = 0; p < c->size; p++) {
+    if (send_counts[p]) PHIP_CHECK_NCCL(g_rccl.Send(d_s + so[(size_t)p], (size_t)send_counts[p], ncclInt32, p, c->nccl, c->ctx->stream));
+    if (recv_counts[p]) PHIP_CHECK_NCCL(g_rccl.Recv(d_r + ro[(size_t)p], (size_t)recv_counts[p], ncclInt32, p, c->nccl, c->ctx->stream));
+  }
+  PHIP_CHECK_NCCL(g_rccl.GroupEnd());
+  if (ro[(size_t)c->size]) PHIP_CHECK_HIP(hipMemcpyAsync(h_recv, d_r, sizeof(int32_t) * ro[(size_t)c->size], hipMemcpyDeviceToHost, c->ctx->stream));
+  PHIP_CHECK_HIP(hipStreamSynchronize(c->ctx->stream));
+  PHIP_CHECK_HIP(hipFree(d_s));
+  PHIP_CHECK_HIP(hipFree(d_r));
+  return 0;
+}
+
+/* ---- ghost exchange ------------------------------------------------------------------------------ */
+/* Pack_1, vpscat.c:494-498: y[i] = x[idx[i]] -- all neighbours' segments in one launch */
+__global__ __launch_bounds__(PHIP_THREADS) void halo_pack_kernel(int32_t n, const int32_t *__restrict__ idx, const double *__restrict__ x, double *__restrict__ y)
+{
+  const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; i < n; i += stride) y[i] = x[idx[i]];
+}
+
+extern "C" int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_procs, const int32_t *to_starts, const int32_t *to_indices,
+                                int32_t from_n, const int32_t *from_procs, const int32_t *from_starts, phip_halo *out)
+{
+  PHIP_REQUIRE(comm && out, PHIP_ERR_ARG_NULL, "phip_halo_create: null argument");
+  PHIP_REQUIRE(to_n >= 0 && from_n >= 0 && to_n < comm->size + 1 && from_n < comm->size + 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_halo_create: %d sends / %d receives on %d ranks", to_n, from_n, comm->size);
+  PHIP_REQUIRE((!to_n || (to_procs && to_starts && to_indices)) && (!from_n || (from_procs && from_starts)), PHIP_ERR_ARG_NULL, "phip_halo_create: null plan array");
+  phip_halo h = new phip_halo_s();
+  h->comm = comm; h->to_n = to_n; h->from_n = from_n;
+  h->to_procs.assign(to_procs, to_procs + to_n);
+  h->to_starts.assign(1, 0); if (to_n) h->to_starts.assign(to_starts, to_starts + to_n + 1);
+  h->from_procs.assign(from_procs, from_procs + from_n);
+  h->from_starts.assign(1, 0); if (from_n) h->from_starts.assign(from_starts, from_starts + from_n + 1);
+  h->nsend = h->to_starts[(size_t)to_n]; h->nrecv = h->from_starts[(size_t)from_n];
+  for (int i = 0; i < to_n; i++) PHIP_REQUIRE(to_procs[i] >= 0 && to_procs[i] < comm->size && to_procs[i] != comm->rank && to_starts[i + 1] >= to_starts[i], PHIP_ERR_ARG_OUTOFRANGE, "phip_halo_create: bad send entry %d", i);
+  for (int i = 0; i < from_n; i++) PHIP_REQUIRE(from_procs[i] >= 0 && from_procs[i] < comm->size && from_procs[i] != comm->rank && from_starts[i + 1] >= from_starts[i], PHIP_ERR_ARG_OUTOFRANGE, "phip_halo_create: bad receive entry %d", i);
+  for (int i = 0; i < h->nsend; i++) PHIP_REQUIRE(to_indices[i] >= 0, PHIP_ERR_ARG_OUTOFRANGE, "phip_halo_create: negative send index");
+  phip_ctx ctx = comm->ctx;
+  PHIP_CHECK_HIP(hipSetDevice(ctx->device));
+  h->d_to_indices = NULL; h->d_sendbuf = NULL; h->lvec = NULL;
+  PHIP_CHECK_HIP(hipMalloc((void **)&h->d_to_indices, sizeof(int32_t) * ((size_t)h->nsend + 4)));
+  PHIP_CHECK_HIP(hipMalloc((void **)&h->d_sendbuf, sizeof(double) * ((size_t)h->nsend + 2)));
+  if (h->nsend) PHIP_CHECK_HIP(hipMemcpyAsync(h->d_to_indices, to_indices, sizeof(int32_t) * (size_t)h->nsend, hipMemcpyHostToDevice, ctx->stream));
+  PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  PHIP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
+  PHIP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+  *out = h;
+  return 0;
+}
+
+extern "C" int phip_halo_destroy(phip_halo h)
+{
+  if (!h) return 0;
+  hipSetDevice(h->comm->ctx->device);
+  hipStreamSynchronize(h->comm->ctx->stream);
+  hipStreamSynchronize(h->comm->ctx->comm_stream);
+  hipFree(h->d_to_indices); hipFree(h->d_sendbuf);
+  hipEventDestroy(h->ev_packed); hipEventDestroy(h->ev_done);
+  delete h;
+  return 0;
+}
+
+extern "C" int phip_halo_begin(phip_halo h, const double *d_x_local, double *d_lvec)
+{
+  PHIP_REQUIRE(h && (d_x_local || !h->nsend) && (d_lvec || !h->nrecv), PHIP_ERR_ARG_NULL, "phip_halo_begin: null argument");
+  phip_comm c = h->comm;
+  phip_ctx  ctx = c->ctx;
+  h->lvec = d_lvec;
+  if (c->size == 1) return 0;
+  if (h->nsend) {
+    hipLaunchKernelGGL(halo_pack_kernel, dim3(phip_grid_for(h->nsend, 1, 1024)), dim3(PHIP_THREADS), 0, ctx->stream, h->nsend, h->d_to_indices, d_x_local, h->d_sendbuf);
+    PHIP_CHECK_HIP(hipGetLastError());
+  }
+  if (c->backend == BACKEND_RCCL) {
+    /* the exchange may start once the pack (and everything before it on the compute stream, e.g. the previous
+       product that still reads lvec) has finished */
+    PHIP_CHECK_HIP(hipEventRecord(h->ev_packed, ctx->stream));
+    PHIP_CHECK_HIP(hipStreamWaitEvent(ctx->comm_stream, h->ev_packed, 0));
+    if (h->to_n || h->from_n) {
+      PHIP_CHECK_NCCL(g_rccl.GroupStart());
+      for (int i = 0; i < h->to_n; i++) {
+        const size_t cnt = (size_t)(h->to_starts[(size_t)i + 1] - h->to_starts[(size_t)i]);
+        if (cnt) PHIP_CHECK_NCCL(g_rccl.Send(h->d_sendbuf + h->to_starts[(size_t)i], cnt, ncclDouble, h->to_procs[(size_t)i], c->nccl, ctx->comm_stream));
+      }
+      for (int i = 0; i < h->from_n; i++) {
+        const size_t cnt = (size_t)(h->from_starts[(size_t)i + 1] - h->from_starts[(size_t)i]);
+        if (cnt) PHIP_CHECK_NCCL(g_rccl.Recv(d_lvec + h->from_starts[(size_t)i], cnt, ncclDouble, h->from_procs[(size_t)i], c->nccl, ctx->comm_stream));
+      }
+      PHIP_CHECK_NCCL(g_rccl.GroupEnd());
+    }
+    PHIP_CHECK_HIP(hipEventRecord(h->ev_done, ctx->comm_stream));
+    return 0;
+  }
+  /* threads: publish the packed buffer; the copies happen in phip_halo_end */
+  PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  c->tg->slot_a[(size_t)c->rank] = h;
+  return 0;
+}
+
+extern "C" int phip_halo_end(phip_halo h)
+{
+  PHIP_REQUIRE(h, PHIP_ERR_ARG_NULL, "phip_halo_end: null halo");
+  phip_comm c = h->comm;
+  phip_ctx  ctx = c->ctx;
+  if (c->size == 1) return 0;
+  if (c->backend == BACKEND_RCCL) {
+    PHIP_CHECK_HIP(hipStreamWaitEvent(ctx->stream, h->ev_done, 0));
+    return 0;
+  }
+  ThreadGroup *g = c->tg;
+  g->barrier();
+  for (int i = 0; i < h->from_n; i++) {
+    const phip_halo_s *peer = (const phip_halo_s *)g->slot_a[(size_t)h->from_procs[(size_t)i]];
+    const int32_t      cnt = h->from_starts[(size_t)i + 1] - h->from_starts[(size_t)i];
+    int                seg = -1;
+    for (int k = 0; k < peer->to_n; k++) if (peer->to_procs[(size_t)k] == c->rank) seg = k;
+    PHIP_REQUIRE(seg >= 0 && peer->to_starts[(size_t)seg + 1] - peer->to_starts[(size_t)seg] == cnt, PHIP_ERR_ARG_SIZ,
+                 "phip_halo_end: rank %d expects %d entries from rank %d, plan mismatch", c->rank, cnt, h->from_procs[(size_t)i]);
+    if (cnt) PHIP_CHECK_HIP(hipMemcpyAsync(h->lvec + h->from_starts[(size_t)i], peer->d_sendbuf + peer->to_starts[(size_t)seg], sizeof(double) * (size_t)cnt, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  g->barrier();
+  return 0;
+}

@@ -1,0 +1,46 @@
+// Internal declarations shared by the libpetschip translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/petschip.h"
+
+#define PHIP_RED_BLOCKS 1024 /* grid of every reduction kernel: fixed => deterministic summation tree */
+#define PHIP_THREADS 256
+
+struct phip_ctx_s {
+  int          device;
+  int          cu_count;
+  hipStream_t  stream;      // compute stream: all kernels, in call order
+  hipStream_t  comm_stream; // ghost exchange, overlapped with the diagonal-block SpMV
+  double      *d_partials;  // [PHIP_MAX_MVEC][PHIP_RED_BLOCKS] block partials of reductions
+  double      *d_result;    // [PHIP_MAX_MVEC] final reduction results (device)
+  double      *h_result;    // pinned host mirror of d_result
+  int         *d_flag;      // small int scratch (jacobi zero flag)
+  int         *h_flag;      // pinned
+};
+
+void phip_set_error(const char *fmt, ...);
+
+#define PHIP_CHECK_HIP(call)                                                                       \
+  do {                                                                                             \
+    hipError_t _e = (call);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      phip_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(_e));    \
+      return PHIP_ERR_LIB;                                                                         \
+    }                                                                                              \
+  } while (0)
+
+#define PHIP_REQUIRE(cond, code, ...)                                                              \
+  do {                                                                                             \
+    if (!(cond)) { phip_set_error(__VA_ARGS__); return (code); }                                   \
+  } while (0)
+
+static inline int phip_grid_for(int64_t n, int per_thread, int maxblocks)
+{
+  int64_t b = (n + (int64_t)PHIP_THREADS * per_thread - 1) / ((int64_t)PHIP_THREADS * per_thread);
+  if (b < 1) b = 1;
+  if (b > maxblocks) b = maxblocks;
+  return (int)b;
+}

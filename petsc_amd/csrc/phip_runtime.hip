@@ -1,0 +1,161 @@
+// Context, memory and error plumbing of libpetschip (see include/petschip.h).
+#include "phip_internal.h"
+#include <stdarg.h>
+#include <stdlib.h>
+
+static thread_local char g_err[512] = "";
+
+void phip_set_error(const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *phip_last_error(void) { return g_err; }
+
+extern "C" int phip_init(int device, phip_ctx *out)
+{
+  PHIP_REQUIRE(out, PHIP_ERR_ARG_NULL, "phip_init: null output");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    phip_set_error("phip_init: no usable HIP device (%s); libpetschip has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "count 0");
+    return PHIP_ERR_LIB;
+  }
+  PHIP_REQUIRE(device >= 0 && device < ndev, PHIP_ERR_ARG_OUTOFRANGE, "phip_init: device %d of %d", device, ndev);
+  PHIP_CHECK_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  PHIP_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  phip_ctx c = (phip_ctx)calloc(1, sizeof(*c));
+  PHIP_REQUIRE(c, PHIP_ERR_MEM, "phip_init: out of host memory");
+  c->device   = device;
+  c->cu_count = prop.multiProcessorCount;
+  PHIP_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  PHIP_CHECK_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  PHIP_CHECK_HIP(hipMalloc((void **)&c->d_partials, sizeof(double) * PHIP_MAX_MVEC * PHIP_RED_BLOCKS));
+  PHIP_CHECK_HIP(hipMalloc((void **)&c->d_result, sizeof(double) * PHIP_MAX_MVEC));
+  PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_result, sizeof(double) * PHIP_MAX_MVEC, hipHostMallocDefault));
+  PHIP_CHECK_HIP(hipMalloc((void **)&c->d_flag, sizeof(int) * 16));
+  PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_flag, sizeof(int) * 16, hipHostMallocDefault));
+  PHIP_CHECK_HIP(hipMemsetAsync(c->d_flag, 0, sizeof(int) * 16, c->stream));
+  PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
+  *out = c;
+  return 0;
+}
+
+extern "C" int phip_finalize(phip_ctx c)
+{
+  if (!c) return 0;
+  PHIP_CHECK_HIP(hipSetDevice(c->device));
+  PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
+  PHIP_CHECK_HIP(hipStreamSynchronize(c->comm_stream));
+  hipFree(c->d_partials); hipFree(c->d_result); hipHostFree(c->h_result); hipFree(c->d_flag); hipHostFree(c->h_flag);
+  hipStreamDestroy(c->stream); hipStreamDestroy(c->comm_stream);
+  free(c);
+  return 0;
+}
+
+extern "C" int phip_device_info(phip_ctx c, int *device, int *cu_count, size_t *hbm_bytes, char *name, int name_len)
+{
+  PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_device_info: null context");
+  hipDeviceProp_t prop;
+  PHIP_CHECK_HIP(hipGetDeviceProperties(&prop, c->device));
+  if (device) *device = c->device;
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+  if (name && name_len > 0) { strncpy(name, prop.gcnArchName, (size_t)name_len - 1); name[name_len - 1] = 0; }
+  return 0;
+}
+
+extern "C" int phip_malloc(phip_ctx c, size_t bytes, void **d_ptr)
+{
+  PHIP_REQUIRE(c && d_ptr, PHIP_ERR_ARG_NULL, "phip_malloc: null argument");
+  *d_ptr = NULL;
+  if (!bytes) bytes = 16; /* zero-length local vectors are legal (veccusp.cu:1017-1020) */
+  hipError_t e = hipMalloc(d_ptr, bytes);
+  if (e != hipSuccess) { phip_set_error("phip_malloc(%zu): %s", bytes, hipGetErrorString(e)); return PHIP_ERR_MEM; }
+  return 0;
+}
+
+extern "C" int phip_free(phip_ctx c, void *d_ptr)
+{
+  (void)c;
+  if (d_ptr) PHIP_CHECK_HIP(hipFree(d_ptr));
+  return 0;
+}
+
+extern "C" int phip_memcpy_h2d(phip_ctx c, void *d_dst, const void *h_src, size_t bytes)
+{
+  PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_memcpy_h2d: null context");
+  if (!bytes) return 0;
+  PHIP_CHECK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+  PHIP_CHECK_HIP(hipStreamSynchronize(c->stream)); /* pageable host source may be reused by the caller at once */
+  return 0;
+}
+
+extern "C" int phip_memcpy_d2h(phip_ctx c, void *h_dst, const void *d_src, size_t bytes)
+{
+  PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_memcpy_d2h: null context");
+  if (bytes) PHIP_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+  PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int phip_memcpy_d2d(phip_ctx c, void *d_dst, const void *d_src, size_t bytes)
+{
+  PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_memcpy_d2d: null context");
+  if (bytes && d_dst != d_src) PHIP_CHECK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int phip_sync(phip_ctx c)
+{
+  PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_sync: null context");
+  PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" void *phip_stream(phip_ctx c) { return c ? (void *)c->stream : NULL; }
+
+extern "C" int phip_read_scalars(phip_ctx c, const double *d_src, int32_t n, double *h_dst)
+{
+  PHIP_REQUIRE(c && h_dst, PHIP_ERR_ARG_NULL, "phip_read_scalars: null argument");
+  PHIP_REQUIRE(n >= 0 && n <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_read_scalars: n=%d", n);
+  if (n) PHIP_CHECK_HIP(hipMemcpyAsync(c->h_result, d_src, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++) h_dst[i] = c->h_result[i];
+  return 0;
+}
+
+extern "C" int phip_event_create(phip_ctx c, void **event)
+{
+  PHIP_REQUIRE(c && event, PHIP_ERR_ARG_NULL, "phip_event_create: null argument");
+  hipEvent_t e;
+  PHIP_CHECK_HIP(hipEventCreate(&e));
+  *event = (void *)e;
+  return 0;
+}
+
+extern "C" int phip_event_record(phip_ctx c, void *event)
+{
+  PHIP_REQUIRE(c && event, PHIP_ERR_ARG_NULL, "phip_event_record: null argument");
+  PHIP_CHECK_HIP(hipEventRecord((hipEvent_t)event, c->stream));
+  return 0;
+}
+
+extern "C" int phip_event_elapsed_ms(phip_ctx c, void *start, void *stop, float *ms)
+{
+  PHIP_REQUIRE(c && start && stop && ms, PHIP_ERR_ARG_NULL, "phip_event_elapsed_ms: null argument");
+  PHIP_CHECK_HIP(hipEventSynchronize((hipEvent_t)stop));
+  PHIP_CHECK_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return 0;
+}
+
+extern "C" int phip_event_destroy(phip_ctx c, void *event)
+{
+  (void)c;
+  if (event) PHIP_CHECK_HIP(hipEventDestroy((hipEvent_t)event));
+  return 0;
+}

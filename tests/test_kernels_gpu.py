@@ -1,0 +1,295 @@
+"""GPU parity tests of the kernel C ABI (libpetschip.so) against the CPU oracle and the golden fixtures.
+
+Tolerances (BASELINE.json): SpMV <= 1e-12 relative in double; index work bit-exact; reductions are compared at
+1e-13 relative to sum|x_i y_i| (the reference pins dot/norm only to 1e-5, src/vec/vec/examples/tests/ex43.c:41-46).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from petsc_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, "mat_%s.npz" % name), allow_pickle=False)
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-300)
+
+
+def gpu_mult(ctx, ai, aj, aa, n, x, cprow=None, y0=None, inplace=False, tpr=0):
+    m = len(ai) - 1
+    A = ctx.mat_create(m, n, ai, aj, aa, cprow)
+    if tpr:
+        ctx.check(ctx.lib.phip_mat_set_threads_per_row(A, tpr))
+    dx = ctx.to_device(x)
+    dy = ctx.to_device(np.full(max(m, 1), 7.25))
+    if y0 is None:
+        ctx.check(ctx.lib.phip_mat_mult(A, dx, dy))
+        out = ctx.to_host(dy, m)
+    else:
+        dy0 = ctx.to_device(y0 if m else np.zeros(1))
+        if inplace:
+            ctx.check(ctx.lib.phip_mat_multadd(A, dx, dy0, dy0))
+            out = ctx.to_host(dy0, m)
+        else:
+            ctx.check(ctx.lib.phip_mat_multadd(A, dx, dy0, dy))
+            out = ctx.to_host(dy, m)
+        ctx.free(dy0)
+    ctx.free(dx); ctx.free(dy)
+    ctx.check(ctx.lib.phip_mat_destroy(A))
+    return out
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_spmv_golden(ctx, orc, golden_dir, name):
+    g = load(golden_dir, name)
+    y = gpu_mult(ctx, g["i"], g["j"], g["a"], int(g["N"]), g["x"])
+    assert relerr(y, g["y"]) <= 1e-12
+    # one lane per row reproduces the reference's k-ascending sum bit for bit (no FMA contraction on either side)
+    yo = orc.matmult(g["i"], g["j"], g["a"], g["x"])
+    y1 = gpu_mult(ctx, g["i"], g["j"], g["a"], int(g["N"]), g["x"], tpr=1)
+    np.testing.assert_array_equal(y1, yo)
+    for tpr in (2, 8, 64):
+        assert relerr(gpu_mult(ctx, g["i"], g["j"], g["a"], int(g["N"]), g["x"], tpr=tpr), g["y"]) <= 1e-12
+    z = gpu_mult(ctx, g["i"], g["j"], g["a"], int(g["N"]), g["x"], y0=g["y0"])
+    assert relerr(z, orc.matmultadd(g["i"], g["j"], g["a"], g["x"], g["y0"])) <= 1e-12
+    z = gpu_mult(ctx, g["i"], g["j"], g["a"], int(g["N"]), g["x"], y0=g["y0"], inplace=True)
+    assert relerr(z, orc.matmultadd(g["i"], g["j"], g["a"], g["x"], g["y0"])) <= 1e-12
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_getdiagonal_golden(ctx, golden_dir, name):
+    g = load(golden_dir, name)
+    m = int(g["M"])
+    A = ctx.mat_create(m, int(g["N"]), g["i"], g["j"], g["a"])
+    dv = ctx.to_device(np.full(m, -3.0))
+    ctx.check(ctx.lib.phip_mat_getdiagonal(A, dv))
+    np.testing.assert_array_equal(ctx.to_host(dv, m), g["diag"])
+    ctx.free(dv); ctx.check(ctx.lib.phip_mat_destroy(A))
+
+
+def test_spmv_stencils_and_rmat(ctx, orc):
+    from petsc_amd import generators as G
+    cases = [G.laplace3d_7pt(24), G.box3d_27pt(17), G.convdiff3d_7pt(19, 13, 11), G.laplace2d_5pt(57, 31), G.rmat(13)]
+    for ai, aj, aa in cases:
+        n = len(ai) - 1
+        x = G.random_vector(n)
+        y = gpu_mult(ctx, ai, aj, aa, n, x)
+        assert relerr(y, orc.matmult(ai, aj, aa, x)) <= 1e-12
+
+
+def test_spmv_long_rows_and_edges(ctx, orc):
+    rng = np.random.default_rng(5)
+    # rows of 0, 1, 2046, 2047, 5000 and 40000 nonzeros around the block capacity; empty leading/trailing rows
+    n = 50000
+    lens = [0, 0, 1, 2046, 2047, 3, 0, 5000, 2045, 2, 40000, 0, 17, 0]
+    ai = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    aj = np.concatenate([np.sort(rng.choice(n, L, replace=False)) for L in lens]).astype(np.int32)
+    aa = rng.standard_normal(len(aj))
+    x = rng.standard_normal(n)
+    y = gpu_mult(ctx, ai, aj, aa, n, x)
+    yo = orc.matmult(ai, aj, aa, x)
+    assert np.abs(y - yo).max() <= 1e-12 * np.abs(aa).max() * np.abs(x).max() * 40000 ** 0.5
+    # empty matrix, matrix with no nonzeros
+    assert len(gpu_mult(ctx, np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0), 0, np.zeros(1))) == 0
+    y = gpu_mult(ctx, np.zeros(6, np.int32), np.zeros(0, np.int32), np.zeros(0), 5, np.ones(5))
+    np.testing.assert_array_equal(y, np.zeros(5))
+
+
+def test_spmv_compressed_row(ctx, orc):
+    """Off-diagonal-block shape: >= 60% empty rows -> Mat_CompressedRow (compressedrow.c:49-72)."""
+    rng = np.random.default_rng(11)
+    m, n = 1000, 300
+    lens = np.where(rng.random(m) < 0.15, rng.integers(1, 9, m), 0)
+    ai = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    aj = np.concatenate([np.sort(rng.choice(n, L, replace=False)) for L in lens if L]).astype(np.int32)
+    aa = rng.standard_normal(len(aj))
+    use, cpi, ridx = orc.check_compressed_row(ai)
+    assert use
+    x = rng.standard_normal(n); y0 = rng.standard_normal(m)
+    y = gpu_mult(ctx, ai, aj, aa, n, x, cprow=(cpi, ridx))
+    np.testing.assert_array_equal(y, orc.matmult(ai, aj, aa, x, cprow=(cpi, ridx)))
+    for inplace in (False, True):
+        z = gpu_mult(ctx, ai, aj, aa, n, x, cprow=(cpi, ridx), y0=y0, inplace=inplace)
+        np.testing.assert_array_equal(z, orc.matmultadd(ai, aj, aa, x, y0, cprow=(cpi, ridx)))
+
+
+def test_plan_covers_rows(ctx):
+    from petsc_amd import generators as G
+    for ai, aj, aa in (G.laplace3d_7pt(20), G.rmat(12)):
+        m = len(ai) - 1
+        A = ctx.mat_create(m, m, ai, aj, aa)
+        p = ctx.mat_plan(A)
+        br = p["block_row"]
+        assert br[0] == 0 and br[-1] == m and np.all(np.diff(br) > 0)
+        nnzb = ai[br[1:]] - ai[br[:-1]]
+        single = np.diff(br) == 1
+        assert np.all((nnzb <= p["cap"]) | single)
+        assert np.all(np.diff(br) <= 256)
+        ctx.check(ctx.lib.phip_mat_destroy(A))
+
+
+def test_mat_create_rejects_bad_input(ctx):
+    from petsc_amd.capi import PhipError
+    with pytest.raises(PhipError):  # column out of range
+        ctx.mat_create(2, 2, np.array([0, 1, 2], np.int32), np.array([0, 5], np.int32), np.ones(2))
+    with pytest.raises(PhipError):  # decreasing row pointer
+        ctx.mat_create(2, 2, np.array([0, 2, 1], np.int32), np.array([0, 1], np.int32), np.ones(2))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 255, 256, 257, 1000, 65537, 1 << 20])
+def test_vec_ops(ctx, orc, n):
+    L = ctx.lib
+    rng = np.random.default_rng(n)
+    x, y, w = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
+    dx, dy, dw = ctx.to_device(x if n else np.zeros(1)), ctx.to_device(y if n else np.zeros(1)), ctx.to_device(w if n else np.zeros(1))
+
+    def reset():
+        if n:
+            ctx.upload(dx, x); ctx.upload(dy, y); ctx.upload(dw, w)
+
+    def tol(ref):
+        return 1e-13 * max(1.0, np.abs(ref).sum() if np.ndim(ref) == 0 else 1.0)
+
+    # reductions
+    s = np.abs(x * y).sum() + 1e-300
+    assert abs(ctx.dot(n, dx, dy) - orc.dot(x, y)) <= 1e-13 * s
+    assert abs(ctx.norm(n, dx, 1) - orc.norm(x, 1)) <= 1e-13 * (np.linalg.norm(x) + 1e-300)
+    assert abs(ctx.norm(n, dx, 0) - orc.norm(x, 0)) <= 1e-13 * (np.abs(x).sum() + 1e-300)
+    assert ctx.norm(n, dx, 3) == orc.norm(x, 3)
+    n1, n2 = ctx.norm(n, dx, 4)
+    assert abs(n1 - orc.norm(x, 0)) <= 1e-13 * (np.abs(x).sum() + 1e-300) and abs(n2 - orc.norm(x, 1)) <= 1e-13 * (np.linalg.norm(x) + 1e-300)
+    # elementwise, including the special-cased scalars of the reference
+    for alpha in (0.0, 1.0, -1.0, 0.37):
+        reset(); ctx.check(L.phip_vec_axpy(ctx.h, n, dy, alpha, dx))
+        np.testing.assert_allclose(ctx.to_host(dy, n), orc.axpy(y, alpha, x), rtol=0, atol=1e-15 * 4)
+        reset(); ctx.check(L.phip_vec_aypx(ctx.h, n, dy, alpha, dx))
+        np.testing.assert_allclose(ctx.to_host(dy, n), orc.aypx(y, alpha, x), rtol=0, atol=1e-15 * 4)
+        reset(); ctx.check(L.phip_vec_waxpy(ctx.h, n, dw, alpha, dx, dy))
+        np.testing.assert_allclose(ctx.to_host(dw, n), orc.waxpy(alpha, x, y), rtol=0, atol=1e-15 * 4)
+        reset(); ctx.check(L.phip_vec_scale(ctx.h, n, dx, alpha))
+        np.testing.assert_array_equal(ctx.to_host(dx, n), orc.scale(x, alpha))
+        for beta in (0.0, 1.0, -2.5):
+            reset(); ctx.check(L.phip_vec_axpby(ctx.h, n, dy, alpha, beta, dx))
+            np.testing.assert_allclose(ctx.to_host(dy, n), orc.axpby(y, alpha, beta, x), rtol=0, atol=1e-14)
+            for gamma in (0.0, 1.0, 0.5):
+                reset(); ctx.check(L.phip_vec_axpbypcz(ctx.h, n, dw, alpha, beta, gamma, dx, dy))
+                np.testing.assert_allclose(ctx.to_host(dw, n), orc.axpbypcz(w, alpha, beta, gamma, x, y), rtol=0, atol=1e-14)
+    reset(); ctx.check(L.phip_vec_pointwise_mult(ctx.h, n, dw, dx, dy))
+    np.testing.assert_array_equal(ctx.to_host(dw, n), orc.pointwisemult(x, y))
+    reset(); ctx.check(L.phip_vec_pointwise_mult(ctx.h, n, dx, dx, dy))  # w aliases x (bvec2.c:94-95)
+    np.testing.assert_array_equal(ctx.to_host(dx, n), orc.pointwisemult(x, y))
+    reset(); ctx.check(L.phip_vec_pointwise_mult(ctx.h, n, dy, dx, dy))  # w aliases y (bvec2.c:96-97)
+    np.testing.assert_array_equal(ctx.to_host(dy, n), orc.pointwisemult(x, y))
+    reset(); ctx.check(L.phip_vec_pointwise_divide(ctx.h, n, dw, dx, dy))
+    np.testing.assert_allclose(ctx.to_host(dw, n), orc.pointwisedivide(x, y), rtol=2e-16, atol=0)
+    reset(); ctx.check(L.phip_vec_copy(ctx.h, n, dx, dw))
+    np.testing.assert_array_equal(ctx.to_host(dw, n), x)
+    for a in (0.0, -1.75):
+        ctx.check(L.phip_vec_set(ctx.h, n, dw, a))
+        np.testing.assert_array_equal(ctx.to_host(dw, n), np.full(n, a))
+    reset(); ctx.check(L.phip_vec_swap(ctx.h, n, dx, dy))
+    np.testing.assert_array_equal(ctx.to_host(dx, n), y); np.testing.assert_array_equal(ctx.to_host(dy, n), x)
+    xz = x.copy()
+    if n > 2:
+        xz[1] = 0.0
+    if n:
+        ctx.upload(dx, xz)
+    ctx.check(L.phip_vec_reciprocal(ctx.h, n, dx))
+    np.testing.assert_allclose(ctx.to_host(dx, n), orc.reciprocal(xz), rtol=2e-16, atol=0)
+    for p in (dx, dy, dw):
+        ctx.free(p)
+
+
+def test_norm_inf_nan(ctx):
+    x = np.ones(1000); x[777] = np.nan
+    dx = ctx.to_device(x)
+    assert np.isnan(ctx.norm(1000, dx, 3))
+    ctx.free(dx)
+
+
+@pytest.mark.parametrize("n", [0, 5, 1003, 300001])
+def test_mdot_maxpy(ctx, orc, n):
+    """ex43.c-style: fused VecMDot equals per-vector VecDot; VecMAXPY equals the oracle's grouped sum."""
+    rng = np.random.default_rng(n + 1)
+    x = rng.standard_normal(n)
+    dx = ctx.to_device(x if n else np.zeros(1))
+    for nv in (1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 30, 31):
+        ys = [rng.standard_normal(n) for _ in range(nv)]
+        dys = [ctx.to_device(y if n else np.zeros(1)) for y in ys]
+        z = ctx.mdot(n, dx, dys)
+        zo = orc.mdot(x, ys)
+        scale = max(1.0, max(np.abs(x * y).sum() for y in ys)) if n else 1.0
+        assert np.abs(z - zo).max() <= 1e-13 * scale
+        for k in range(nv):
+            assert abs(z[k] - ctx.dot(n, dx, dys[k])) <= 1e-13 * scale
+        al = rng.standard_normal(nv)
+        if n:
+            ctx.upload(dx, x)
+        ctx.maxpy(n, dx, al, dys)
+        ref = orc.maxpy(x, al, ys)
+        assert np.abs(ctx.to_host(dx, n) - ref).max() <= 1e-13 * (1 + np.abs(al).sum() * 6) if n else True
+        if n:
+            ctx.upload(dx, x)
+        for p in dys:
+            ctx.free(p)
+    ctx.free(dx)
+
+
+def test_jacobi_setup(ctx, orc):
+    d = np.array([2.0, 0.0, -4.0, 1e-300, 5.0])
+    for useabs in (0, 1):
+        dd = ctx.to_device(d)
+        import ctypes
+        flag = ctypes.c_int(-1)
+        ctx.check(ctx.lib.phip_jacobi_setup(ctx.h, len(d), dd, useabs, 0, ctypes.byref(flag)))
+        np.testing.assert_array_equal(ctx.to_host(dd, len(d)), orc.jacobi_setup(d, bool(useabs)))
+        assert flag.value == 1
+        ctx.free(dd)
+
+
+def test_self_comm_and_reduce_local(ctx):
+    import ctypes as C
+    comm = C.c_void_p()
+    ctx.check(ctx.lib.phip_comm_create(ctx.h, b"self", None, 1, 0, C.byref(comm)))
+    x = np.arange(1, 101, dtype=float)
+    dx = ctx.to_device(x)
+    dout = ctx.malloc(8 * 4)
+    ctx.check(ctx.lib.phip_vec_reduce_local(ctx.h, 1, 100, dx, 1, None, dout))
+    ctx.check(ctx.lib.phip_comm_allreduce(comm, dout, 1, 0))
+    z = (C.c_double * 1)()
+    ctx.check(ctx.lib.phip_read_scalars(ctx.h, dout, 1, z))
+    assert z[0] == float((x * x).sum())
+    ctx.check(ctx.lib.phip_comm_destroy(comm))
+    ctx.free(dx); ctx.free(dout)
+
+
+def test_rccl_single_rank(ctx):
+    """RCCL smoke on one GPU: unique id, init, all-reduce of one rank, a self send/recv ghost exchange."""
+    import ctypes as C
+    idb = C.create_string_buffer(128)
+    ctx.check(ctx.lib.phip_comm_unique_id(idb))
+    comm = C.c_void_p()
+    ctx.check(ctx.lib.phip_comm_create(ctx.h, b"rccl", idb, 1, 0, C.byref(comm)))
+    dbuf = ctx.to_device(np.array([1.5, -2.0, 3.25]))
+    ctx.check(ctx.lib.phip_comm_allreduce(comm, dbuf, 3, 0))
+    np.testing.assert_array_equal(ctx.to_host(dbuf, 3), [1.5, -2.0, 3.25])
+    gathered = np.zeros(1, np.int32)
+    mine = np.array([42], np.int32)
+    ctx.check(ctx.lib.phip_comm_allgather_host(comm, mine.ctypes.data_as(C.c_void_p), gathered.ctypes.data_as(C.c_void_p), 4))
+    assert gathered[0] == 42
+    ctx.check(ctx.lib.phip_comm_destroy(comm))
+    ctx.free(dbuf)
