@@ -19,6 +19,9 @@
  *     call order; calls that return a host scalar (dot/norm/mdot) synchronise that stream, everything
  *     else is asynchronous.  Contexts are not thread-safe (PETSc 3.6 objects are not either).
  *   - There is no CPU fallback: without a usable GPU phip_init fails with PHIP_ERR_LIB.
+ *   - phip_init(-1, ...) makes a PLANNING-ONLY context for hosts without a GPU: index work (row-block plan, ghost plan, set-up
+ *     collectives) runs; uploads are dropped; every numerical entry point fails with PHIP_ERR_SUP.  It exists for CPU-side tests
+ *     of the host logic and never computes anything.
  */
 #ifndef PETSCHIP_H
 #define PETSCHIP_H
@@ -132,6 +135,11 @@ int phip_read_scalars(phip_ctx ctx, const double *d_src, int32_t n, double *h_ds
  * phip_comm_unique_id and handed to every rank by the embedding application (bench.py uses torch.distributed).
  * backend "self": size-1 communicator, no library needed.  backend "threads": ranks are host threads of ONE process
  * sharing one GPU (test harness for the distributed code path on a single-GPU box; id128 then holds a group key). */
+typedef int (*phip_allgather_fn)(void *user, const void *h_send, void *h_recv, size_t bytes_per_rank);
+typedef int (*phip_alltoallv_i32_fn)(void *user, const int32_t *h_send, const int32_t *send_counts, int32_t *h_recv, const int32_t *recv_counts);
+/* A communicator whose SET-UP collectives are supplied by the embedding application (host MPI inside PETSc, torch.distributed/gloo in
+ * the CPU tests).  It carries no device traffic: phip_comm_allreduce / phip_halo_begin fail with PHIP_ERR_SUP on it. */
+int phip_comm_create_callbacks(phip_ctx ctx, int nranks, int rank, phip_allgather_fn allgather, phip_alltoallv_i32_fn alltoallv, void *user, phip_comm *comm);
 int phip_comm_unique_id(void *id128);
 int phip_comm_create(phip_ctx ctx, const char *backend, const void *id128, int nranks, int rank, phip_comm *comm);
 int phip_comm_destroy(phip_comm comm);

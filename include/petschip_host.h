@@ -1,0 +1,200 @@
+/*
+ * petschip_host.h -- C ABI of libpetschip_host.so: a stand-alone mirror of the slice of the PETSc 3.6.1 C API
+ * that drives the sparse-solve hot path (MatCreate/MatSetValues/MatAssembly*, VecCreate/..., PCJACOBI, KSPCG,
+ * KSPGMRES), with the SAME names, argument meaning and error behaviour as the reference, so that the reference's
+ * own example programs for this path translate line by line and the parity tests read like the reference's tests.
+ *
+ * Why it exists: PETSc itself cannot be configured in this image, and only this repository travels to
+ * the GPU box.  Inside a real PETSc the same kernels are reached through the glue shown in INTEGRATION.md, which
+ * binds include/petschip.h; this header is the harness that runs them without PETSc.
+ *
+ * Only the HIP types exist here: MATSEQAIJHIP / MATMPIAIJHIP / MATAIJHIP and VECSEQHIP / VECMPIHIP / VECHIP.  There is no
+ * CPU implementation behind these names; every numerical operation runs on the GPU through libpetschip.so.
+ *
+ * Type registration follows the reference (string-keyed constructor lists): MatRegister (src/mat/interface/matreg.c:160),
+ * VecRegister (src/vec/vec/interface/vecreg.c:126), base-name dispatch by communicator size (matreg.c:47-57).
+ */
+#ifndef PETSCHIP_HOST_H
+#define PETSCHIP_HOST_H
+
+#include <stdint.h>
+#include "petschip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int     PetscErrorCode;
+typedef int32_t PetscInt;
+typedef double  PetscScalar;
+typedef double  PetscReal;
+typedef int     PetscBool;
+#define PETSC_TRUE 1
+#define PETSC_FALSE 0
+#define PETSC_DECIDE (-1)
+#define PETSC_DETERMINE PETSC_DECIDE
+#define PETSC_DEFAULT (-2)
+
+typedef struct _p_PetscComm *PetscComm; /* stands in for MPI_Comm: one rank per GPU */
+typedef struct _p_Vec *Vec;
+typedef struct _p_Mat *Mat;
+typedef struct _p_PC  *PC;
+typedef struct _p_KSP *KSP;
+
+typedef enum { NOT_SET_VALUES = 0, INSERT_VALUES = 1, ADD_VALUES = 2 } InsertMode;             /* include/petscsys.h */
+typedef enum { MAT_FLUSH_ASSEMBLY = 1, MAT_FINAL_ASSEMBLY = 0 } MatAssemblyType;               /* include/petscmat.h */
+typedef enum { NORM_1 = 0, NORM_2 = 1, NORM_FROBENIUS = 2, NORM_INFINITY = 3, NORM_1_AND_2 = 4 } NormType; /* petscvec.h:155 */
+typedef enum { KSP_NORM_DEFAULT = -1, KSP_NORM_NONE = 0, KSP_NORM_PRECONDITIONED = 1, KSP_NORM_UNPRECONDITIONED = 2, KSP_NORM_NATURAL = 3 } KSPNormType; /* petscksp.h:322 */
+typedef enum { KSP_GMRES_CGS_REFINE_NEVER = 0, KSP_GMRES_CGS_REFINE_IFNEEDED = 1, KSP_GMRES_CGS_REFINE_ALWAYS = 2 } KSPGMRESCGSRefinementType;
+typedef enum { PC_JACOBI_DIAGONAL = 0, PC_JACOBI_ROWMAX = 1, PC_JACOBI_ROWSUM = 2 } PCJacobiType;
+typedef enum { /* include/petscksp.h:385-405 */
+  KSP_CONVERGED_RTOL = 2, KSP_CONVERGED_ATOL = 3, KSP_CONVERGED_ITS = 4, KSP_DIVERGED_NULL = -2, KSP_DIVERGED_ITS = -3,
+  KSP_DIVERGED_DTOL = -4, KSP_DIVERGED_BREAKDOWN = -5, KSP_DIVERGED_INDEFINITE_PC = -8, KSP_DIVERGED_NANORINF = -9,
+  KSP_DIVERGED_INDEFINITE_MAT = -10, KSP_CONVERGED_ITERATING = 0
+} KSPConvergedReason;
+
+#define VECSEQHIP "seqhip"
+#define VECMPIHIP "mpihip"
+#define VECHIP "hip"
+#define MATSEQAIJHIP "seqaijhip"
+#define MATMPIAIJHIP "mpiaijhip"
+#define MATAIJHIP "aijhip"
+#define KSPCG "cg"
+#define KSPGMRES "gmres"
+#define PCNONE "none"
+#define PCJACOBI "jacobi"
+
+/* ---- start-up (PetscInitialize's role for this slice).  backend: "self" | "rccl" | "threads" (see petschip.h) ---- */
+PetscErrorCode PetscHipInitialize(int device, const char *backend, const void *id128, int nranks, int rank, PetscComm *world);
+/* the same with the set-up collectives supplied by the application (host MPI inside PETSc; gloo in the CPU tests).
+ * device = -1 gives a planning-only context: assembly, MatSetUpMultiply and the scatter plan run, numerical calls fail. */
+PetscErrorCode PetscHipInitializeWithCallbacks(int device, int nranks, int rank, phip_allgather_fn allgather, phip_alltoallv_i32_fn alltoallv, void *user, PetscComm *world);
+PetscErrorCode PetscHipFinalize(PetscComm *world);
+PetscErrorCode PetscCommGetSelf(PetscComm world, PetscComm *self);     /* PETSC_COMM_SELF */
+PetscErrorCode PetscCommRankSize(PetscComm comm, int *rank, int *size); /* MPI_Comm_rank / MPI_Comm_size */
+PetscErrorCode PetscCommGetContext(PetscComm comm, phip_ctx *ctx);
+const char    *PetscHipLastError(void);
+/* PetscSplitOwnership, src/sys/utils/psplit.c:75-97 */
+PetscErrorCode PetscSplitOwnership(PetscComm comm, PetscInt *n, PetscInt *N);
+
+/* ---- Vec (include/petscvec.h; wrappers src/vec/vec/interface/{vector.c,rvector.c}) ---- */
+PetscErrorCode VecRegister(const char *sname, PetscErrorCode (*ctor)(Vec));
+PetscErrorCode VecCreate(PetscComm comm, Vec *v);
+PetscErrorCode VecSetSizes(Vec v, PetscInt n, PetscInt N);
+PetscErrorCode VecSetType(Vec v, const char *type);
+PetscErrorCode VecGetType(Vec v, const char **type);
+PetscErrorCode VecDuplicate(Vec v, Vec *w);
+PetscErrorCode VecDuplicateVecs(Vec v, PetscInt m, Vec **V);
+PetscErrorCode VecDestroyVecs(PetscInt m, Vec **V);
+PetscErrorCode VecDestroy(Vec *v);
+PetscErrorCode VecGetSize(Vec v, PetscInt *N);
+PetscErrorCode VecGetLocalSize(Vec v, PetscInt *n);
+PetscErrorCode VecGetOwnershipRange(Vec v, PetscInt *low, PetscInt *high);
+PetscErrorCode VecSetValues(Vec v, PetscInt ni, const PetscInt ix[], const PetscScalar y[], InsertMode iora); /* locally owned entries only */
+PetscErrorCode VecAssemblyBegin(Vec v);
+PetscErrorCode VecAssemblyEnd(Vec v);
+PetscErrorCode VecGetArray(Vec v, PetscScalar **a);
+PetscErrorCode VecRestoreArray(Vec v, PetscScalar **a);
+PetscErrorCode VecGetArrayRead(Vec v, const PetscScalar **a);
+PetscErrorCode VecRestoreArrayRead(Vec v, const PetscScalar **a);
+PetscErrorCode VecHipGetArrayRead(Vec v, const PetscScalar **d_a);  /* device pointer; cf. VecCUSPGetArrayRead veccusp.cu:1993 */
+PetscErrorCode VecHipGetArrayWrite(Vec v, PetscScalar **d_a);       /* device pointer, marks the vector changed */
+PetscErrorCode VecSet(Vec x, PetscScalar alpha);
+PetscErrorCode VecCopy(Vec x, Vec y);
+PetscErrorCode VecSwap(Vec x, Vec y);
+PetscErrorCode VecScale(Vec x, PetscScalar alpha);
+PetscErrorCode VecAXPY(Vec y, PetscScalar alpha, Vec x);
+PetscErrorCode VecAYPX(Vec y, PetscScalar alpha, Vec x);
+PetscErrorCode VecAXPBY(Vec y, PetscScalar alpha, PetscScalar beta, Vec x);
+PetscErrorCode VecWAXPY(Vec w, PetscScalar alpha, Vec x, Vec y);
+PetscErrorCode VecAXPBYPCZ(Vec z, PetscScalar alpha, PetscScalar beta, PetscScalar gamma, Vec x, Vec y);
+PetscErrorCode VecMAXPY(Vec y, PetscInt nv, const PetscScalar alpha[], Vec x[]);
+PetscErrorCode VecPointwiseMult(Vec w, Vec x, Vec y);
+PetscErrorCode VecPointwiseDivide(Vec w, Vec x, Vec y);
+PetscErrorCode VecReciprocal(Vec x);
+PetscErrorCode VecDot(Vec x, Vec y, PetscScalar *val);
+PetscErrorCode VecTDot(Vec x, Vec y, PetscScalar *val);
+PetscErrorCode VecMDot(Vec x, PetscInt nv, const Vec y[], PetscScalar val[]);
+PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val);
+PetscErrorCode VecNormalize(Vec x, PetscReal *val);
+
+/* ---- Mat (include/petscmat.h; wrappers src/mat/interface/matrix.c) ---- */
+PetscErrorCode MatRegister(const char *sname, PetscErrorCode (*ctor)(Mat));
+PetscErrorCode MatCreate(PetscComm comm, Mat *A);
+PetscErrorCode MatSetSizes(Mat A, PetscInt m, PetscInt n, PetscInt M, PetscInt N);
+PetscErrorCode MatSetType(Mat A, const char *type);
+PetscErrorCode MatGetType(Mat A, const char **type);
+PetscErrorCode MatSetUp(Mat A);
+PetscErrorCode MatSeqAIJSetPreallocation(Mat A, PetscInt nz, const PetscInt nnz[]);
+PetscErrorCode MatMPIAIJSetPreallocation(Mat A, PetscInt d_nz, const PetscInt d_nnz[], PetscInt o_nz, const PetscInt o_nnz[]);
+PetscErrorCode MatSetValues(Mat A, PetscInt m, const PetscInt idxm[], PetscInt n, const PetscInt idxn[], const PetscScalar v[], InsertMode addv);
+PetscErrorCode MatAssemblyBegin(Mat A, MatAssemblyType type);
+PetscErrorCode MatAssemblyEnd(Mat A, MatAssemblyType type);
+PetscErrorCode MatZeroEntries(Mat A);
+/* MatZeroRows with x = b = NULL (src/mat/interface/matrix.c:5564): global row numbers, pattern kept, diag on the diagonal */
+PetscErrorCode MatZeroRows(Mat A, PetscInt numRows, const PetscInt rows[], PetscScalar diag, Vec x, Vec b);
+PetscErrorCode MatCreateSeqAIJWithArrays(PetscComm comm, PetscInt m, PetscInt n, PetscInt i[], PetscInt j[], PetscScalar a[], Mat *A);       /* aij.c:4027: arrays are copied here */
+PetscErrorCode MatCreateMPIAIJWithArrays(PetscComm comm, PetscInt m, PetscInt n, PetscInt M, PetscInt N, const PetscInt i[], const PetscInt j[], const PetscScalar a[], Mat *A); /* mpiaij.c:3647 */
+PetscErrorCode MatGetSize(Mat A, PetscInt *M, PetscInt *N);
+PetscErrorCode MatGetLocalSize(Mat A, PetscInt *m, PetscInt *n);
+PetscErrorCode MatGetOwnershipRange(Mat A, PetscInt *rstart, PetscInt *rend);
+PetscErrorCode MatCreateVecs(Mat A, Vec *right, Vec *left);
+PetscErrorCode MatMult(Mat A, Vec x, Vec y);
+PetscErrorCode MatMultAdd(Mat A, Vec x, Vec y, Vec z);
+PetscErrorCode MatGetDiagonal(Mat A, Vec v);
+PetscErrorCode MatGetRowMaxAbs(Mat A, Vec v, PetscInt idx[]);
+PetscErrorCode MatGetRowSum(Mat A, Vec v);
+PetscErrorCode MatDestroy(Mat *A);
+/* Introspection used by the index-parity tests (bit-exact against the reference's assembly products):
+ * which: 0 = the SeqAIJ itself / the diagonal block A of an MPIAIJ, 1 = the off-diagonal block B.
+ * Any output pointer may be NULL.  cprow_i / cprow_rindex are filled only when *cprow_use != 0. */
+PetscErrorCode MatHipGetBlockInfo(Mat A, int which, PetscInt *m, PetscInt *n, PetscInt *nz, PetscInt *nonzerorowcnt, PetscInt *rmax, PetscBool *cprow_use, PetscInt *cprow_nrows);
+PetscErrorCode MatHipGetBlockArrays(Mat A, int which, PetscInt *i, PetscInt *j, PetscScalar *a, PetscInt *diag, PetscInt *cprow_i, PetscInt *cprow_rindex);
+/* MPIAIJ multiply set-up products: garray (mmaij.c:69-101) and the VecScatter PtoS plan (vpscat.c:2297-2495) */
+PetscErrorCode MatHipGetGhostInfo(Mat A, PetscInt *ec, PetscInt *to_n, PetscInt *to_len, PetscInt *from_n);
+PetscErrorCode MatHipGetGhostArrays(Mat A, PetscInt *garray, PetscInt *to_procs, PetscInt *to_starts, PetscInt *to_indices, PetscInt *from_procs, PetscInt *from_starts);
+/* MatLoad / MatView / VecLoad / VecView on the PetscBinary format (aij.c:547-582,4109-4177; mpiaij.c:2890-3089; src/vec/vec/utils/vecio.c):
+ * big-endian, header {MAT_FILE_CLASSID 1211216, M, N, nz}, rowlens[M], j[nz], a[nz]; Vec {1211214, N}, values[N].
+ * The viewer is a plain file position: *offset is advanced past the object read or written (several objects per file). */
+PetscErrorCode MatLoad(Mat A, const char *filename, int64_t *offset);
+PetscErrorCode VecLoad(Vec v, const char *filename, int64_t *offset);
+PetscErrorCode MatView(Mat A, const char *filename, int append);
+PetscErrorCode VecView(Vec v, const char *filename, int append);
+
+/* ---- PC (include/petscpc.h) ---- */
+PetscErrorCode PCCreate(PetscComm comm, PC *pc);
+PetscErrorCode PCSetType(PC pc, const char *type);
+PetscErrorCode PCSetOperators(PC pc, Mat Amat, Mat Pmat);
+PetscErrorCode PCSetUp(PC pc);
+PetscErrorCode PCApply(PC pc, Vec x, Vec y);
+PetscErrorCode PCApplySymmetricLeft(PC pc, Vec x, Vec y);
+PetscErrorCode PCApplySymmetricRight(PC pc, Vec x, Vec y);
+PetscErrorCode PCJacobiSetType(PC pc, PCJacobiType type);
+PetscErrorCode PCJacobiSetUseAbs(PC pc, PetscBool flg);
+PetscErrorCode PCDestroy(PC *pc);
+
+/* ---- KSP (include/petscksp.h) ---- */
+PetscErrorCode KSPCreate(PetscComm comm, KSP *ksp);
+PetscErrorCode KSPSetType(KSP ksp, const char *type);
+PetscErrorCode KSPSetOperators(KSP ksp, Mat Amat, Mat Pmat);
+PetscErrorCode KSPGetPC(KSP ksp, PC *pc);
+PetscErrorCode KSPSetTolerances(KSP ksp, PetscReal rtol, PetscReal abstol, PetscReal dtol, PetscInt maxits);
+PetscErrorCode KSPSetInitialGuessNonzero(KSP ksp, PetscBool flg);
+PetscErrorCode KSPSetNormType(KSP ksp, KSPNormType normtype);
+PetscErrorCode KSPGMRESSetRestart(KSP ksp, PetscInt restart);
+PetscErrorCode KSPGMRESSetCGSRefinementType(KSP ksp, KSPGMRESCGSRefinementType type);
+PetscErrorCode KSPGMRESSetHapTol(KSP ksp, PetscReal tol);
+PetscErrorCode KSPCGSetSingleReduction(KSP ksp, PetscBool flg); /* -ksp_cg_single_reduction, cg.c:226-243,262-268 */
+PetscErrorCode KSPSetResidualHistory(KSP ksp, PetscReal a[], PetscInt na, PetscBool reset);
+PetscErrorCode KSPGetResidualHistory(KSP ksp, PetscReal **a, PetscInt *na);
+PetscErrorCode KSPSetUp(KSP ksp);
+PetscErrorCode KSPSolve(KSP ksp, Vec b, Vec x);
+PetscErrorCode KSPGetIterationNumber(KSP ksp, PetscInt *its);
+PetscErrorCode KSPGetConvergedReason(KSP ksp, KSPConvergedReason *reason);
+PetscErrorCode KSPGetResidualNorm(KSP ksp, PetscReal *rnorm);
+PetscErrorCode KSPDestroy(KSP *ksp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,2155 @@
+// libpetschip_host.so -- stand-alone mirror of the PETSc 3.6.1 API slice that drives the sparse-solve hot path
+// (include/petschip_host.h).  Host logic only: every numerical operation is a call into libpetschip.so (HIP).
+// Cites are file:line under the PETSc 3.6.1 reference tree.
+#include "../../../include/petschip_host.h"
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#define PETSC_ERR_MEM 55
+#define PETSC_ERR_SUP 56
+#define PETSC_ERR_ORDER 58
+#define PETSC_ERR_ARG_SIZ 60
+#define PETSC_ERR_ARG_IDN 61
+#define PETSC_ERR_ARG_WRONG 62
+#define PETSC_ERR_ARG_OUTOFRANGE 63
+#define PETSC_ERR_FILE_OPEN 65
+#define PETSC_ERR_FILE_READ 66
+#define PETSC_ERR_FILE_WRITE 67
+#define PETSC_ERR_ARG_WRONGSTATE 73
+#define PETSC_ERR_ARG_INCOMP 75
+#define PETSC_ERR_LIB 76
+#define PETSC_ERR_FILE_UNEXPECTED 79
+#define PETSC_ERR_ARG_NULL 85
+#define PETSC_ERR_ARG_UNKNOWN_TYPE 86
+#define PETSC_ERR_ARG_TYPENOTSET 89
+
+#define MAT_FILE_CLASSID 1211216 /* include/petscmat.h, bin/PetscBinaryIO.py:129-163 */
+#define VEC_FILE_CLASSID 1211214
+
+static thread_local char g_herr[640] = "";
+static PetscErrorCode seterr(PetscErrorCode code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_herr, sizeof(g_herr), fmt, ap);
+  va_end(ap);
+  return code;
+}
+extern "C" const char *PetscHipLastError(void) { return g_herr; }
+
+#define SETERRQ(code, ...) return seterr((code), __VA_ARGS__)
+#define CHKERRQ(ierr) do { if (ierr) return (ierr); } while (0)
+#define CHKPHIP(call) do { int _rc = (call); if (_rc) return seterr(_rc, "%s", phip_last_error()); } while (0)
+
+/* ================================================================================================ */
+struct _p_PetscComm {
+  phip_ctx  ctx;
+  phip_comm comm;
+  int       rank, size;
+  bool      is_world;
+  double   *d_red; /* device scratch for distributed reductions: PHIP_MAX_MVEC doubles */
+  _p_PetscComm *self;
+};
+
+extern "C" PetscErrorCode PetscHipInitialize(int device, const char *backend, const void *id128, int nranks, int rank, PetscComm *world)
+{
+  if (!world || !backend) SETERRQ(PETSC_ERR_ARG_NULL, "PetscHipInitialize: null argument");
+  PetscComm w = new _p_PetscComm();
+  memset(w, 0, sizeof(*w));
+  CHKPHIP(phip_init(device, &w->ctx));
+  CHKPHIP(phip_comm_create(w->ctx, backend, id128, nranks, rank, &w->comm));
+  w->rank = rank; w->size = nranks; w->is_world = true;
+  CHKPHIP(phip_malloc(w->ctx, sizeof(double) * PHIP_MAX_MVEC, (void **)&w->d_red));
+  PetscComm s = new _p_PetscComm();
+  memset(s, 0, sizeof(*s));
+  s->ctx = w->ctx; s->rank = 0; s->size = 1; s->is_world = false; s->d_red = w->d_red;
+  CHKPHIP(phip_comm_create(w->ctx, "self", NULL, 1, 0, &s->comm));
+  s->self = s; w->self = s;
+  *world = w;
+  return 0;
+}
+
+/* Set-up collectives supplied by the embedding application (host MPI in PETSc, gloo in the CPU tests); device < 0 gives a
+   planning-only context (include/petschip.h) */
+extern "C" PetscErrorCode PetscHipInitializeWithCallbacks(int device, int nranks, int rank, phip_allgather_fn allgather, phip_alltoallv_i32_fn alltoallv, void *user, PetscComm *world)
+{
+  if (!world) SETERRQ(PETSC_ERR_ARG_NULL, "PetscHipInitializeWithCallbacks: null argument");
+  PetscComm w = new _p_PetscComm();
+  memset(w, 0, sizeof(*w));
+  CHKPHIP(phip_init(device, &w->ctx));
+  CHKPHIP(phip_comm_create_callbacks(w->ctx, nranks, rank, allgather, alltoallv, user, &w->comm));
+  w->rank = rank; w->size = nranks; w->is_world = true;
+  CHKPHIP(phip_malloc(w->ctx, sizeof(double) * PHIP_MAX_MVEC, (void **)&w->d_red));
+  PetscComm s = new _p_PetscComm();
+  memset(s, 0, sizeof(*s));
+  s->ctx = w->ctx; s->rank = 0; s->size = 1; s->is_world = false; s->d_red = w->d_red;
+  CHKPHIP(phip_comm_create(w->ctx, "self", NULL, 1, 0, &s->comm));
+  s->self = s; w->self = s;
+  *world = w;
+  return 0;
+}
+
+static bool ctx_has_device(phip_ctx ctx)
+{
+  int dev = -1;
+  phip_device_info(ctx, &dev, NULL, NULL, NULL, 0);
+  return dev >= 0;
+}
+
+extern "C" PetscErrorCode PetscHipFinalize(PetscComm *world)
+{
+  if (!world || !*world) return 0;
+  PetscComm w = *world;
+  phip_comm_destroy(w->self->comm);
+  phip_comm_destroy(w->comm);
+  phip_free(w->ctx, w->d_red);
+  phip_finalize(w->ctx);
+  delete w->self;
+  delete w;
+  *world = NULL;
+  return 0;
+}
+
+extern "C" PetscErrorCode PetscCommGetSelf(PetscComm world, PetscComm *self)
+{
+  if (!world || !self) SETERRQ(PETSC_ERR_ARG_NULL, "PetscCommGetSelf: null argument");
+  *self = world->self;
+  return 0;
+}
+extern "C" PetscErrorCode PetscCommRankSize(PetscComm c, int *rank, int *size)
+{
+  if (!c) SETERRQ(PETSC_ERR_ARG_NULL, "PetscCommRankSize: null communicator");
+  if (rank) *rank = c->rank;
+  if (size) *size = c->size;
+  return 0;
+}
+extern "C" PetscErrorCode PetscCommGetContext(PetscComm c, phip_ctx *ctx)
+{
+  if (!c || !ctx) SETERRQ(PETSC_ERR_ARG_NULL, "PetscCommGetContext: null argument");
+  *ctx = c->ctx;
+  return 0;
+}
+
+/* PetscSplitOwnership, src/sys/utils/psplit.c:75-97 */
+extern "C" PetscErrorCode PetscSplitOwnership(PetscComm comm, PetscInt *n, PetscInt *N)
+{
+  if (!comm || !n || !N) SETERRQ(PETSC_ERR_ARG_NULL, "PetscSplitOwnership: null argument");
+  if (*N == PETSC_DECIDE && *n == PETSC_DECIDE) SETERRQ(PETSC_ERR_ARG_INCOMP, "Both n and N cannot be PETSC_DECIDE");
+  if (*N == PETSC_DECIDE) {
+    std::vector<PetscInt> all((size_t)comm->size);
+    CHKPHIP(phip_comm_allgather_host(comm->comm, n, all.data(), sizeof(PetscInt)));
+    PetscInt s = 0;
+    for (int r = 0; r < comm->size; r++) s += all[(size_t)r];
+    *N = s;
+  } else if (*n == PETSC_DECIDE) {
+    *n = *N / comm->size + ((*N % comm->size) > comm->rank); /* psplit.c:88 */
+  }
+  return 0;
+}
+
+/* PetscLayoutSetUp, src/vec/is/utils/pmap.c:133-158: ranges = prefix sums of the local sizes */
+static PetscErrorCode layout_setup(PetscComm comm, PetscInt *n, PetscInt *N, std::vector<PetscInt> &range)
+{
+  PetscErrorCode ierr = PetscSplitOwnership(comm, n, N); CHKERRQ(ierr);
+  std::vector<PetscInt> all((size_t)comm->size);
+  CHKPHIP(phip_comm_allgather_host(comm->comm, n, all.data(), sizeof(PetscInt)));
+  range.assign((size_t)comm->size + 1, 0);
+  for (int r = 0; r < comm->size; r++) range[(size_t)r + 1] = range[(size_t)r] + all[(size_t)r];
+  if (range[(size_t)comm->size] != *N) SETERRQ(PETSC_ERR_ARG_SIZ, "Sum of local lengths %d does not equal global length %d", range[(size_t)comm->size], *N);
+  return 0;
+}
+
+/* ================================================================================================ */
+/* Vec                                                                                              */
+struct _VecOps { /* the slots of include/petsc/private/vecimpl.h:20-96 that this slice fills */
+  PetscErrorCode (*duplicate)(Vec, Vec *);
+  PetscErrorCode (*dot)(Vec, Vec, PetscScalar *);
+  PetscErrorCode (*tdot)(Vec, Vec, PetscScalar *);
+  PetscErrorCode (*mdot)(Vec, PetscInt, const Vec[], PetscScalar *);
+  PetscErrorCode (*norm)(Vec, NormType, PetscReal *);
+  PetscErrorCode (*scale)(Vec, PetscScalar);
+  PetscErrorCode (*copy)(Vec, Vec);
+  PetscErrorCode (*set)(Vec, PetscScalar);
+  PetscErrorCode (*swap)(Vec, Vec);
+  PetscErrorCode (*axpy)(Vec, PetscScalar, Vec);
+  PetscErrorCode (*axpby)(Vec, PetscScalar, PetscScalar, Vec);
+  PetscErrorCode (*maxpy)(Vec, PetscInt, const PetscScalar *, Vec *);
+  PetscErrorCode (*aypx)(Vec, PetscScalar, Vec);
+  PetscErrorCode (*waxpy)(Vec, PetscScalar, Vec, Vec);
+  PetscErrorCode (*axpbypcz)(Vec, PetscScalar, PetscScalar, PetscScalar, Vec, Vec);
+  PetscErrorCode (*pointwisemult)(Vec, Vec, Vec);
+  PetscErrorCode (*pointwisedivide)(Vec, Vec, Vec);
+  PetscErrorCode (*reciprocal)(Vec);
+  PetscErrorCode (*destroy)(Vec);
+};
+
+struct _p_Vec {
+  PetscComm   comm;
+  std::string type;
+  PetscInt    n, N;
+  std::vector<PetscInt> range;
+  bool        setup;
+  double     *d;          /* device array */
+  std::vector<double> h;  /* host mirror handed out by VecGetArray */
+  int         host_out;   /* 0 none, 1 read access outstanding, 2 write access outstanding */
+  uint64_t    state;      /* PetscObjectState: bumped on every write (rvector.c:1865 et al.) */
+  std::vector<PetscInt> stash_i; std::vector<double> stash_v; std::vector<int> stash_mode;
+  _VecOps     ops;
+};
+
+static std::map<std::string, PetscErrorCode (*)(Vec)> &VecList()
+{
+  static std::map<std::string, PetscErrorCode (*)(Vec)> l;
+  return l;
+}
+static void VecRegisterAll();
+
+extern "C" PetscErrorCode VecRegister(const char *sname, PetscErrorCode (*ctor)(Vec))
+{
+  if (!sname || !ctor) SETERRQ(PETSC_ERR_ARG_NULL, "VecRegister: null argument");
+  VecList()[sname] = ctor;
+  return 0;
+}
+
+extern "C" PetscErrorCode VecCreate(PetscComm comm, Vec *v)
+{
+  if (!comm || !v) SETERRQ(PETSC_ERR_ARG_NULL, "VecCreate: null argument");
+  Vec x = new _p_Vec();
+  x->comm = comm; x->n = PETSC_DECIDE; x->N = PETSC_DECIDE; x->setup = false; x->d = NULL; x->host_out = 0; x->state = 0;
+  memset(&x->ops, 0, sizeof(x->ops));
+  *v = x;
+  return 0;
+}
+
+extern "C" PetscErrorCode VecSetSizes(Vec v, PetscInt n, PetscInt N)
+{
+  if (!v) SETERRQ(PETSC_ERR_ARG_NULL, "VecSetSizes: null vector");
+  if (N >= 0 && n > N) SETERRQ(PETSC_ERR_ARG_INCOMP, "Local size %d cannot be larger than global size %d", n, N);
+  if (v->setup) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Cannot change/reset vector sizes after the type has been set");
+  v->n = n; v->N = N;
+  return 0;
+}
+
+#define VCTX(v) ((v)->comm->ctx)
+#define VecCheckReady(v, name) do { if (!(v)) SETERRQ(PETSC_ERR_ARG_NULL, name ": null vector"); if (!(v)->setup) SETERRQ(PETSC_ERR_ARG_TYPENOTSET, name ": vector type/sizes not set"); if ((v)->host_out == 2) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, name ": VecGetArray() is outstanding; call VecRestoreArray() first"); } while (0)
+#define VecCheckSame(x, y, name) do { if ((x)->n != (y)->n || (x)->N != (y)->N) SETERRQ(PETSC_ERR_ARG_INCOMP, name ": incompatible vector lengths (local %d vs %d, global %d vs %d)", (x)->n, (y)->n, (x)->N, (y)->N); } while (0)
+
+/* ---- HIP implementations of the ops: Seq versions, then the MPI reductions ---- */
+static PetscErrorCode VecDuplicate_HIP(Vec v, Vec *w);
+static PetscErrorCode VecDestroy_HIP(Vec v) { if (v->d) CHKPHIP(phip_free(VCTX(v), v->d)); v->d = NULL; return 0; }
+static PetscErrorCode VecDot_SeqHIP(Vec x, Vec y, PetscScalar *z) { CHKPHIP(phip_vec_dot(VCTX(x), x->n, x->d, y->d, z)); return 0; }
+static PetscErrorCode VecNorm_SeqHIP(Vec x, NormType t, PetscReal *z) { CHKPHIP(phip_vec_norm(VCTX(x), x->n, x->d, (int)t, z)); return 0; }
+static PetscErrorCode VecMDot_SeqHIP(Vec x, PetscInt nv, const Vec y[], PetscScalar *z)
+{
+  std::vector<const double *> p((size_t)nv);
+  for (PetscInt k = 0; k < nv; k++) p[(size_t)k] = y[k]->d;
+  CHKPHIP(phip_vec_mdot(VCTX(x), x->n, x->d, nv, p.data(), z));
+  return 0;
+}
+/* VecDot_MPI pbvec.c:9-19: local dot, MPI_Allreduce(SUM) -> here the local result stays on the device for RCCL */
+static PetscErrorCode VecDot_MPIHIP(Vec x, Vec y, PetscScalar *z)
+{
+  const double *p[1] = {y->d};
+  CHKPHIP(phip_vec_reduce_local(VCTX(x), 0, x->n, x->d, 1, p, x->comm->d_red));
+  CHKPHIP(phip_comm_allreduce(x->comm->comm, x->comm->d_red, 1, 0));
+  CHKPHIP(phip_read_scalars(VCTX(x), x->comm->d_red, 1, z));
+  return 0;
+}
+/* VecMDot_MPI pvec2.c:10-25: one all-reduce of nv scalars */
+static PetscErrorCode VecMDot_MPIHIP(Vec x, PetscInt nv, const Vec y[], PetscScalar *z)
+{
+  if (nv > PHIP_MAX_MVEC) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "VecMDot: nv=%d exceeds %d", nv, PHIP_MAX_MVEC);
+  std::vector<const double *> p((size_t)nv);
+  for (PetscInt k = 0; k < nv; k++) p[(size_t)k] = y[k]->d;
+  CHKPHIP(phip_vec_reduce_local(VCTX(x), 0, x->n, x->d, nv, p.data(), x->comm->d_red));
+  CHKPHIP(phip_comm_allreduce(x->comm->comm, x->comm->d_red, nv, 0));
+  CHKPHIP(phip_read_scalars(VCTX(x), x->comm->d_red, nv, z));
+  return 0;
+}
+/* VecNorm_MPI pvec2.c:49-85 */
+static PetscErrorCode VecNorm_MPIHIP(Vec x, NormType t, PetscReal *z)
+{
+  double *dr = x->comm->d_red;
+  double  r[2];
+  switch (t) {
+  case NORM_2: case NORM_FROBENIUS:
+    CHKPHIP(phip_vec_reduce_local(VCTX(x), 1, x->n, x->d, 1, NULL, dr));
+    CHKPHIP(phip_comm_allreduce(x->comm->comm, dr, 1, 0));
+    CHKPHIP(phip_read_scalars(VCTX(x), dr, 1, r));
+    *z = sqrt(r[0]);
+    return 0;
+  case NORM_1:
+    CHKPHIP(phip_vec_reduce_local(VCTX(x), 2, x->n, x->d, 1, NULL, dr));
+    CHKPHIP(phip_comm_allreduce(x->comm->comm, dr, 1, 0));
+    CHKPHIP(phip_read_scalars(VCTX(x), dr, 1, z));
+    return 0;
+  case NORM_INFINITY:
+    CHKPHIP(phip_vec_reduce_local(VCTX(x), 3, x->n, x->d, 1, NULL, dr));
+    CHKPHIP(phip_comm_allreduce(x->comm->comm, dr, 1, 1));
+    CHKPHIP(phip_read_scalars(VCTX(x), dr, 1, z));
+    return 0;
+  case NORM_1_AND_2:
+    CHKPHIP(phip_vec_reduce_local(VCTX(x), 4, x->n, x->d, 1, NULL, dr));
+    CHKPHIP(phip_comm_allreduce(x->comm->comm, dr, 2, 0));
+    CHKPHIP(phip_read_scalars(VCTX(x), dr, 2, r));
+    z[0] = r[0]; z[1] = sqrt(r[1]);
+    return 0;
+  }
+  SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "VecNorm: unknown NormType %d", (int)t);
+}
+static PetscErrorCode VecScale_HIP(Vec x, PetscScalar a) { CHKPHIP(phip_vec_scale(VCTX(x), x->n, x->d, a)); return 0; }
+static PetscErrorCode VecCopy_HIP(Vec x, Vec y) { CHKPHIP(phip_vec_copy(VCTX(x), x->n, x->d, y->d)); return 0; }
+static PetscErrorCode VecSet_HIP(Vec x, PetscScalar a) { CHKPHIP(phip_vec_set(VCTX(x), x->n, x->d, a)); return 0; }
+static PetscErrorCode VecSwap_HIP(Vec x, Vec y) { CHKPHIP(phip_vec_swap(VCTX(x), x->n, x->d, y->d)); return 0; }
+static PetscErrorCode VecAXPY_HIP(Vec y, PetscScalar a, Vec x) { CHKPHIP(phip_vec_axpy(VCTX(y), y->n, y->d, a, x->d)); return 0; }
+static PetscErrorCode VecAXPBY_HIP(Vec y, PetscScalar a, PetscScalar b, Vec x) { CHKPHIP(phip_vec_axpby(VCTX(y), y->n, y->d, a, b, x->d)); return 0; }
+static PetscErrorCode VecMAXPY_HIP(Vec y, PetscInt nv, const PetscScalar *al, Vec *x)
+{
+  std::vector<const double *> p((size_t)nv);
+  for (PetscInt k = 0; k < nv; k++) p[(size_t)k] = x[k]->d;
+  CHKPHIP(phip_vec_maxpy(VCTX(y), y->n, y->d, nv, al, p.data()));
+  return 0;
+}
+static PetscErrorCode VecAYPX_HIP(Vec y, PetscScalar a, Vec x) { CHKPHIP(phip_vec_aypx(VCTX(y), y->n, y->d, a, x->d)); return 0; }
+static PetscErrorCode VecWAXPY_HIP(Vec w, PetscScalar a, Vec x, Vec y) { CHKPHIP(phip_vec_waxpy(VCTX(w), w->n, w->d, a, x->d, y->d)); return 0; }
+static PetscErrorCode VecAXPBYPCZ_HIP(Vec z, PetscScalar a, PetscScalar b, PetscScalar g, Vec x, Vec y) { CHKPHIP(phip_vec_axpbypcz(VCTX(z), z->n, z->d, a, b, g, x->d, y->d)); return 0; }
+static PetscErrorCode VecPointwiseMult_HIP(Vec w, Vec x, Vec y) { CHKPHIP(phip_vec_pointwise_mult(VCTX(w), w->n, w->d, x->d, y->d)); return 0; }
+static PetscErrorCode VecPointwiseDivide_HIP(Vec w, Vec x, Vec y) { CHKPHIP(phip_vec_pointwise_divide(VCTX(w), w->n, w->d, x->d, y->d)); return 0; }
+static PetscErrorCode VecReciprocal_HIP(Vec x) { CHKPHIP(phip_vec_reciprocal(VCTX(x), x->n, x->d)); return 0; }
+
+static PetscErrorCode vec_alloc(Vec v)
+{
+  PetscErrorCode ierr = layout_setup(v->comm, &v->n, &v->N, v->range); CHKERRQ(ierr);
+  CHKPHIP(phip_malloc(VCTX(v), sizeof(double) * (size_t)v->n, (void **)&v->d));
+  if (ctx_has_device(VCTX(v))) CHKPHIP(phip_vec_set(VCTX(v), v->n, v->d, 0.0)); /* new vectors are zeroed (bvec2.c:873 VecCreate_Seq_Private + calloc) */
+  v->setup = true;
+  return 0;
+}
+
+static void vec_fill_ops(Vec v, bool mpi)
+{
+  v->ops.duplicate = VecDuplicate_HIP; v->ops.destroy = VecDestroy_HIP;
+  v->ops.dot = mpi ? VecDot_MPIHIP : VecDot_SeqHIP; v->ops.tdot = v->ops.dot; /* real scalars: TDot == Dot */
+  v->ops.mdot = mpi ? VecMDot_MPIHIP : VecMDot_SeqHIP;
+  v->ops.norm = mpi ? VecNorm_MPIHIP : VecNorm_SeqHIP;
+  v->ops.scale = VecScale_HIP; v->ops.copy = VecCopy_HIP; v->ops.set = VecSet_HIP; v->ops.swap = VecSwap_HIP;
+  v->ops.axpy = VecAXPY_HIP; v->ops.axpby = VecAXPBY_HIP; v->ops.maxpy = VecMAXPY_HIP; v->ops.aypx = VecAYPX_HIP;
+  v->ops.waxpy = VecWAXPY_HIP; v->ops.axpbypcz = VecAXPBYPCZ_HIP; v->ops.pointwisemult = VecPointwiseMult_HIP;
+  v->ops.pointwisedivide = VecPointwiseDivide_HIP; v->ops.reciprocal = VecReciprocal_HIP;
+}
+
+/* constructors: the analogue of VecCreate_SeqCUSP veccusp.cu:1714+ / VecCreate_MPICUSP mpicusp.cu:188-233 / VecCreate_CUSP :237-250 */
+static PetscErrorCode VecCreate_SeqHIP(Vec v)
+{
+  if (v->comm->size > 1) SETERRQ(PETSC_ERR_ARG_WRONG, "Cannot create VECSEQHIP on more than one process");
+  vec_fill_ops(v, false);
+  v->type = VECSEQHIP;
+  return vec_alloc(v);
+}
+static PetscErrorCode VecCreate_MPIHIP(Vec v)
+{
+  vec_fill_ops(v, true);
+  v->type = VECMPIHIP;
+  return vec_alloc(v);
+}
+static PetscErrorCode VecCreate_HIP(Vec v) { return (v->comm->size == 1) ? VecCreate_SeqHIP(v) : VecCreate_MPIHIP(v); }
+
+static void VecRegisterAll()
+{
+  static bool done = false;
+  if (done) return;
+  done = true;
+  VecRegister(VECSEQHIP, VecCreate_SeqHIP);
+  VecRegister(VECMPIHIP, VecCreate_MPIHIP);
+  VecRegister(VECHIP, VecCreate_HIP);
+}
+
+extern "C" PetscErrorCode VecSetType(Vec v, const char *type)
+{
+  if (!v || !type) SETERRQ(PETSC_ERR_ARG_NULL, "VecSetType: null argument");
+  VecRegisterAll();
+  auto it = VecList().find(type);
+  if (it == VecList().end()) SETERRQ(PETSC_ERR_ARG_UNKNOWN_TYPE, "Unknown vector type: %s", type); /* vecreg.c:55 */
+  if (v->setup) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "VecSetType: type already set to %s", v->type.c_str());
+  if (v->n == PETSC_DECIDE && v->N == PETSC_DECIDE) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "VecSetType: call VecSetSizes() first");
+  return (*it->second)(v);
+}
+extern "C" PetscErrorCode VecGetType(Vec v, const char **type)
+{
+  if (!v || !type) SETERRQ(PETSC_ERR_ARG_NULL, "VecGetType: null argument");
+  *type = v->type.c_str();
+  return 0;
+}
+
+static PetscErrorCode VecDuplicate_HIP(Vec v, Vec *w)
+{
+  Vec x = new _p_Vec();
+  x->comm = v->comm; x->type = v->type; x->n = v->n; x->N = v->N; x->range = v->range; x->setup = true; x->host_out = 0; x->state = 0;
+  x->ops = v->ops; x->d = NULL;
+  CHKPHIP(phip_malloc(VCTX(v), sizeof(double) * (size_t)v->n, (void **)&x->d));
+  if (ctx_has_device(VCTX(v))) CHKPHIP(phip_vec_set(VCTX(v), x->n, x->d, 0.0));
+  *w = x;
+  return 0;
+}
+extern "C" PetscErrorCode VecDuplicate(Vec v, Vec *w)
+{
+  VecCheckReady(v, "VecDuplicate");
+  if (!w) SETERRQ(PETSC_ERR_ARG_NULL, "VecDuplicate: null output");
+  return (*v->ops.duplicate)(v, w);
+}
+/* VecDuplicateVecs_Default, src/vec/vec/interface/vector.c:830: m separate duplicates */
+extern "C" PetscErrorCode VecDuplicateVecs(Vec v, PetscInt m, Vec **V)
+{
+  VecCheckReady(v, "VecDuplicateVecs");
+  if (m <= 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "m must be > 0: m = %d", m);
+  Vec *a = (Vec *)calloc((size_t)m, sizeof(Vec));
+  for (PetscInt i = 0; i < m; i++) { PetscErrorCode ierr = VecDuplicate(v, &a[i]); CHKERRQ(ierr); }
+  *V = a;
+  return 0;
+}
+extern "C" PetscErrorCode VecDestroy(Vec *v)
+{
+  if (!v || !*v) return 0;
+  if ((*v)->ops.destroy) { PetscErrorCode ierr = (*(*v)->ops.destroy)(*v); CHKERRQ(ierr); }
+  delete *v;
+  *v = NULL;
+  return 0;
+}
+extern "C" PetscErrorCode VecDestroyVecs(PetscInt m, Vec **V)
+{
+  if (!V || !*V) return 0;
+  for (PetscInt i = 0; i < m; i++) { PetscErrorCode ierr = VecDestroy(&(*V)[i]); CHKERRQ(ierr); }
+  free(*V);
+  *V = NULL;
+  return 0;
+}
+extern "C" PetscErrorCode VecGetSize(Vec v, PetscInt *N) { VecCheckReady(v, "VecGetSize"); *N = v->N; return 0; }
+extern "C" PetscErrorCode VecGetLocalSize(Vec v, PetscInt *n) { VecCheckReady(v, "VecGetLocalSize"); *n = v->n; return 0; }
+extern "C" PetscErrorCode VecGetOwnershipRange(Vec v, PetscInt *low, PetscInt *high)
+{
+  VecCheckReady(v, "VecGetOwnershipRange");
+  if (low) *low = v->range[(size_t)v->comm->rank];
+  if (high) *high = v->range[(size_t)v->comm->rank + 1];
+  return 0;
+}
+
+extern "C" PetscErrorCode VecGetArrayRead(Vec v, const PetscScalar **a)
+{
+  VecCheckReady(v, "VecGetArrayRead");
+  v->h.resize((size_t)v->n + 1);
+  CHKPHIP(phip_memcpy_d2h(VCTX(v), v->h.data(), v->d, sizeof(double) * (size_t)v->n));
+  v->host_out = 1;
+  *a = v->h.data();
+  return 0;
+}
+extern "C" PetscErrorCode VecRestoreArrayRead(Vec v, const PetscScalar **a)
+{
+  if (!v) SETERRQ(PETSC_ERR_ARG_NULL, "VecRestoreArrayRead: null vector");
+  v->host_out = 0;
+  if (a) *a = NULL;
+  return 0;
+}
+extern "C" PetscErrorCode VecGetArray(Vec v, PetscScalar **a)
+{
+  const PetscScalar *r;
+  PetscErrorCode     ierr = VecGetArrayRead(v, &r); CHKERRQ(ierr);
+  v->host_out = 2;
+  *a = v->h.data();
+  return 0;
+}
+extern "C" PetscErrorCode VecRestoreArray(Vec v, PetscScalar **a)
+{
+  if (!v) SETERRQ(PETSC_ERR_ARG_NULL, "VecRestoreArray: null vector");
+  if (v->host_out != 2) SETERRQ(PETSC_ERR_ORDER, "VecRestoreArray: no VecGetArray() outstanding");
+  CHKPHIP(phip_memcpy_h2d(VCTX(v), v->d, v->h.data(), sizeof(double) * (size_t)v->n));
+  v->host_out = 0;
+  v->state++; /* rvector.c:1865 */
+  if (a) *a = NULL;
+  return 0;
+}
+extern "C" PetscErrorCode VecHipGetArrayRead(Vec v, const PetscScalar **d_a) { VecCheckReady(v, "VecHipGetArrayRead"); *d_a = v->d; return 0; }
+extern "C" PetscErrorCode VecHipGetArrayWrite(Vec v, PetscScalar **d_a) { VecCheckReady(v, "VecHipGetArrayWrite"); *d_a = v->d; v->state++; return 0; }
+
+extern "C" PetscErrorCode VecSetValues(Vec v, PetscInt ni, const PetscInt ix[], const PetscScalar y[], InsertMode iora)
+{
+  VecCheckReady(v, "VecSetValues");
+  const PetscInt lo = v->range[(size_t)v->comm->rank], hi = v->range[(size_t)v->comm->rank + 1];
+  for (PetscInt k = 0; k < ni; k++) {
+    if (ix[k] < 0) continue; /* negative indices are ignored (bvec2.c VecSetValues_Seq) */
+    if (ix[k] >= v->N) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Out of range index value %d maximum %d", ix[k], v->N);
+    if (ix[k] < lo || ix[k] >= hi) SETERRQ(PETSC_ERR_SUP, "VecSetValues: entry %d is owned by another process; only locally owned entries are supported", ix[k]);
+    v->stash_i.push_back(ix[k] - lo); v->stash_v.push_back(y[k]); v->stash_mode.push_back((int)iora);
+  }
+  return 0;
+}
+extern "C" PetscErrorCode VecAssemblyBegin(Vec v) { VecCheckReady(v, "VecAssemblyBegin"); return 0; }
+extern "C" PetscErrorCode VecAssemblyEnd(Vec v)
+{
+  VecCheckReady(v, "VecAssemblyEnd");
+  if (v->stash_i.empty()) return 0;
+  PetscScalar   *a;
+  PetscErrorCode ierr = VecGetArray(v, &a); CHKERRQ(ierr);
+  for (size_t k = 0; k < v->stash_i.size(); k++) {
+    if (v->stash_mode[k] == ADD_VALUES) a[v->stash_i[k]] += v->stash_v[k]; else a[v->stash_i[k]] = v->stash_v[k];
+  }
+  v->stash_i.clear(); v->stash_v.clear(); v->stash_mode.clear();
+  return VecRestoreArray(v, &a);
+}
+
+/* ---- interface wrappers (argument checks + dispatch + state bump), rvector.c / vector.c ---- */
+extern "C" PetscErrorCode VecSet(Vec x, PetscScalar alpha)
+{
+  VecCheckReady(x, "VecSet");
+  PetscErrorCode ierr = (*x->ops.set)(x, alpha); CHKERRQ(ierr);
+  x->state++;
+  return 0;
+}
+extern "C" PetscErrorCode VecCopy(Vec x, Vec y)
+{
+  VecCheckReady(x, "VecCopy"); VecCheckReady(y, "VecCopy");
+  if (x == y) return 0; /* vector.c:1643 */
+  VecCheckSame(x, y, "VecCopy");
+  PetscErrorCode ierr = (*x->ops.copy)(x, y); CHKERRQ(ierr);
+  y->state++;
+  return 0;
+}
+extern "C" PetscErrorCode VecSwap(Vec x, Vec y)
+{
+  VecCheckReady(x, "VecSwap"); VecCheckReady(y, "VecSwap"); VecCheckSame(x, y, "VecSwap");
+  PetscErrorCode ierr = (*x->ops.swap)(x, y); CHKERRQ(ierr);
+  x->state++; y->state++;
+  return 0;
+}
+extern "C" PetscErrorCode VecScale(Vec x, PetscScalar alpha)
+{
+  VecCheckReady(x, "VecScale");
+  if (alpha != 1.0) { /* rvector.c:514 */
+    PetscErrorCode ierr = (*x->ops.scale)(x, alpha); CHKERRQ(ierr);
+    x->state++;
+  }
+  return 0;
+}
+extern "C" PetscErrorCode VecAXPY(Vec y, PetscScalar alpha, Vec x)
+{
+  VecCheckReady(x, "VecAXPY"); VecCheckReady(y, "VecAXPY"); VecCheckSame(x, y, "VecAXPY");
+  if (x == y) SETERRQ(PETSC_ERR_ARG_IDN, "x and y cannot be the same vector"); /* rvector.c:638 */
+  PetscErrorCode ierr = (*y->ops.axpy)(y, alpha, x); CHKERRQ(ierr);
+  y->state++;
+  return 0;
+}
+extern "C" PetscErrorCode VecAYPX(Vec y, PetscScalar alpha, Vec x)
+{
+  VecCheckReady(x, "VecAYPX"); VecCheckReady(y, "VecAYPX"); VecCheckSame(x, y, "VecAYPX");
+  if (x == y) SETERRQ(PETSC_ERR_ARG_IDN, "x and y must be different vectors");
+  PetscErrorCode ierr = (*y->ops.aypx)(y, alpha, x); CHKERRQ(ierr);
+  y->state++;
+  return 0;
+}
+extern "C" PetscErrorCode VecAXPBY(Vec y, PetscScalar alpha, PetscScalar beta, Vec x)
+{
+  VecCheckReady(x, "VecAXPBY"); VecCheckReady(y, "VecAXPBY"); VecCheckSame(x, y, "VecAXPBY");
+  PetscErrorCode ierr = (*y->ops.axpby)(y, alpha, beta, x); CHKERRQ(ierr);
+  y->state++;
+  return 0;
+}
+extern "C" PetscErrorCode VecWAXPY(Vec w, PetscScalar alpha, Vec x, Vec y)
+{
+  VecCheckReady(w, "VecWAXPY"); VecCheckReady(x, "VecWAXPY"); VecCheckReady(y, "VecWAXPY"); VecCheckSame(x, y, "VecWAXPY"); VecCheckSame(w, x, "VecWAXPY");
+  if (w == y) SETERRQ(PETSC_ERR_SUP, "Result vector w cannot be same as input vector y, suggest VecAXPY()"); /* rvector.c:758 */
+  if (w == x) SETERRQ(PETSC_ERR_SUP, "Result vector w cannot be same as input vector x, suggest VecAYPX()");
+  PetscErrorCode ierr = (*w->ops.waxpy)(w, alpha, x, y); CHKERRQ(ierr);
+  w->state++;
+  return 0;
+}
+extern "C" PetscErrorCode VecAXPBYPCZ(Vec z, PetscScalar alpha, PetscScalar beta, PetscScalar gamma, Vec x, Vec y)
+{
+  VecCheckReady(z, "VecAXPBYPCZ"); VecCheckReady(x, "VecAXPBYPCZ"); VecCheckReady(y, "VecAXPBYPCZ"); VecCheckSame(x, y, "VecAXPBYPCZ"); VecCheckSame(z, x, "VecAXPBYPCZ");
+  PetscErrorCode ierr = (*z->ops.axpbypcz)(z, alpha, beta, gamma, x, y); CHKERRQ(ierr);
+  z->state++;
+  return 0;
+}
+extern "C" PetscErrorCode VecMAXPY(Vec y, PetscInt nv, const PetscScalar alpha[], Vec x[])
+{
+  VecCheckReady(y, "VecMAXPY");
+  if (!nv) return 0;                                                         /* rvector.c:1271 */
+  if (nv < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Number of vectors (given %d) cannot be negative", nv);
+  for (PetscInt k = 0; k < nv; k++) { VecCheckReady(x[k], "VecMAXPY"); VecCheckSame(y, x[k], "VecMAXPY"); }
+  PetscErrorCode ierr = (*y->ops.maxpy)(y, nv, alpha, x); CHKERRQ(ierr);
+  y->state++;
+  return 0;
+}
+extern "C" PetscErrorCode VecPointwiseMult(Vec w, Vec x, Vec y)
+{
+  VecCheckReady(w, "VecPointwiseMult"); VecCheckReady(x, "VecPointwiseMult"); VecCheckReady(y, "VecPointwiseMult"); VecCheckSame(x, y, "VecPointwiseMult"); VecCheckSame(w, x, "VecPointwiseMult");
+  PetscErrorCode ierr = (*w->ops.pointwisemult)(w, x, y); CHKERRQ(ierr);
+  w->state++;
+  return 0;
+}
+extern "C" PetscErrorCode VecPointwiseDivide(Vec w, Vec x, Vec y)
+{
+  VecCheckReady(w, "VecPointwiseDivide"); VecCheckReady(x, "VecPointwiseDivide"); VecCheckReady(y, "VecPointwiseDivide"); VecCheckSame(x, y, "VecPointwiseDivide"); VecCheckSame(w, x, "VecPointwiseDivide");
+  PetscErrorCode ierr = (*w->ops.pointwisedivide)(w, x, y); CHKERRQ(ierr);
+  w->state++;
+  return 0;
+}
+extern "C" PetscErrorCode VecReciprocal(Vec x)
+{
+  VecCheckReady(x, "VecReciprocal");
+  PetscErrorCode ierr = (*x->ops.reciprocal)(x); CHKERRQ(ierr);
+  x->state++;
+  return 0;
+}
+extern "C" PetscErrorCode VecDot(Vec x, Vec y, PetscScalar *val)
+{
+  VecCheckReady(x, "VecDot"); VecCheckReady(y, "VecDot"); VecCheckSame(x, y, "VecDot");
+  if (!val) SETERRQ(PETSC_ERR_ARG_NULL, "VecDot: null result");
+  return (*x->ops.dot)(x, y, val);
+}
+extern "C" PetscErrorCode VecTDot(Vec x, Vec y, PetscScalar *val)
+{
+  VecCheckReady(x, "VecTDot"); VecCheckReady(y, "VecTDot"); VecCheckSame(x, y, "VecTDot");
+  if (!val) SETERRQ(PETSC_ERR_ARG_NULL, "VecTDot: null result");
+  return (*x->ops.tdot)(x, y, val);
+}
+extern "C" PetscErrorCode VecMDot(Vec x, PetscInt nv, const Vec y[], PetscScalar val[])
+{
+  VecCheckReady(x, "VecMDot");
+  if (!nv) return 0;                                                         /* rvector.c:1226 */
+  if (nv < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Number of vectors (given %d) cannot be negative", nv);
+  for (PetscInt k = 0; k < nv; k++) { VecCheckReady(y[k], "VecMDot"); VecCheckSame(x, y[k], "VecMDot"); }
+  return (*x->ops.mdot)(x, nv, y, val);
+}
+extern "C" PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val)
+{
+  VecCheckReady(x, "VecNorm");
+  if (!val) SETERRQ(PETSC_ERR_ARG_NULL, "VecNorm: null result");
+  return (*x->ops.norm)(x, type, val);
+}
+/* VecNormalize rvector.c:328-347: skip scaling when the norm is 0 or 1; scale by tmp = 1.0/norm */
+extern "C" PetscErrorCode VecNormalize(Vec x, PetscReal *val)
+{
+  PetscReal      norm;
+  PetscErrorCode ierr = VecNorm(x, NORM_2, &norm); CHKERRQ(ierr);
+  if (norm != 0.0 && norm != 1.0) {
+    const PetscScalar tmp = 1.0 / norm;
+    ierr = VecScale(x, tmp); CHKERRQ(ierr);
+  }
+  if (val) *val = norm;
+  return 0;
+}
+
+/* ================================================================================================ */
+/* Host CSR under assembly (Mat_SeqAIJ: i, j, a, imax/ilen, diag, compressedrow; aij.h:10-38,106-124)  */
+struct HostAIJ {
+  PetscInt m = 0, n = 0;
+  std::vector<int64_t>  start;     /* first slot of each row in j/a */
+  std::vector<PetscInt> len, cap;  /* ilen / imax */
+  std::vector<PetscInt> j;
+  std::vector<double>   a;
+  bool     relocated = false;      /* some row was moved to the tail of j/a */
+  bool     assembled = false;
+  uint64_t nonzerostate = 0, dev_nonzerostate = ~0ull;
+  bool     values_dirty = false;
+  /* assembly products (aij.c:968-1024) */
+  std::vector<PetscInt> ai, diag, cprow_i, cprow_rindex;
+  PetscInt nz = 0, nonzerorowcnt = 0, rmax = 0;
+  bool     cprow_use = false;
+  phip_mat dev = NULL;
+
+  void prealloc(PetscInt m_, PetscInt n_, PetscInt nzrow, const PetscInt *nnz)
+  {
+    m = m_; n = n_;
+    start.assign((size_t)m + 1, 0); len.assign((size_t)m, 0); cap.assign((size_t)m, 0);
+    int64_t tot = 0;
+    for (PetscInt r = 0; r < m; r++) { cap[(size_t)r] = nnz ? nnz[r] : nzrow; start[(size_t)r] = tot; tot += cap[(size_t)r]; }
+    start[(size_t)m] = tot;
+    j.assign((size_t)tot, 0); a.assign((size_t)tot, 0.0);
+    relocated = false; assembled = false; nonzerostate++;
+  }
+  /* sorted insert of one entry: MatSetValues_SeqAIJ aij.c:465-494 */
+  void set(PetscInt row, PetscInt col, double v, bool add)
+  {
+    PetscInt *rp = j.data() + start[(size_t)row];
+    PetscInt  nrow = len[(size_t)row];
+    PetscInt *pos = std::lower_bound(rp, rp + nrow, col);
+    size_t    k = (size_t)(pos - rp);
+    if (k < (size_t)nrow && *pos == col) {
+      double &t = a[(size_t)start[(size_t)row] + k];
+      if (add) t += v; else t = v;
+      values_dirty = true;
+      return;
+    }
+    if (nrow >= cap[(size_t)row]) { /* no room: move the row to the tail with more slack (role of MatSeqXAIJReallocateAIJ, aij.h:148-179) */
+      const PetscInt newcap = cap[(size_t)row] * 2 + 15;
+      const size_t   old = (size_t)start[(size_t)row], tail = j.size();
+      j.resize(tail + (size_t)newcap); a.resize(tail + (size_t)newcap);
+      std::copy(j.begin() + (long)old, j.begin() + (long)old + nrow, j.begin() + (long)tail);
+      std::copy(a.begin() + (long)old, a.begin() + (long)old + nrow, a.begin() + (long)tail);
+      start[(size_t)row] = (int64_t)tail; cap[(size_t)row] = newcap; relocated = true;
+    }
+    const size_t s = (size_t)start[(size_t)row];
+    for (size_t q = (size_t)nrow; q > k; q--) { j[s + q] = j[s + q - 1]; a[s + q] = a[s + q - 1]; }
+    j[s + k] = col; a[s + k] = v;
+    len[(size_t)row] = nrow + 1;
+    nonzerostate++; values_dirty = true;
+  }
+  /* MatAssemblyEnd_SeqAIJ aij.c:968-1024 */
+  void assembly_end()
+  {
+    int64_t tot = 0;
+    for (PetscInt r = 0; r < m; r++) tot += len[(size_t)r];
+    bool slack = relocated;
+    for (PetscInt r = 0; r < m && !slack; r++) slack = cap[(size_t)r] != len[(size_t)r];
+    if (slack) {
+      if (!relocated) { /* rows are in order: squeeze forward in place (aij.c:981-995) */
+        int64_t w = 0;
+        for (PetscInt r = 0; r < m; r++) {
+          const int64_t s = start[(size_t)r];
+          const PetscInt L = len[(size_t)r];
+          if (w != s) for (PetscInt q = 0; q < L; q++) { j[(size_t)(w + q)] = j[(size_t)(s + q)]; a[(size_t)(w + q)] = a[(size_t)(s + q)]; }
+          start[(size_t)r] = w; w += L;
+        }
+        j.resize((size_t)tot); a.resize((size_t)tot);
+      } else {
+        std::vector<PetscInt> nj((size_t)tot); std::vector<double> na((size_t)tot);
+        int64_t w = 0;
+        for (PetscInt r = 0; r < m; r++) {
+          const int64_t s = start[(size_t)r];
+          const PetscInt L = len[(size_t)r];
+          std::copy(j.begin() + (long)s, j.begin() + (long)s + L, nj.begin() + (long)w);
+          std::copy(a.begin() + (long)s, a.begin() + (long)s + L, na.begin() + (long)w);
+          start[(size_t)r] = w; w += L;
+        }
+        j.swap(nj); a.swap(na);
+      }
+      start[(size_t)m] = tot;
+      for (PetscInt r = 0; r < m; r++) cap[(size_t)r] = len[(size_t)r];
+      relocated = false;
+    }
+    finish_products();
+  }
+  void finish_products()
+  {
+    ai.assign((size_t)m + 1, 0);
+    nonzerorowcnt = 0; rmax = 0;
+    for (PetscInt r = 0; r < m; r++) {
+      ai[(size_t)r + 1] = ai[(size_t)r] + len[(size_t)r];
+      nonzerorowcnt += len[(size_t)r] > 0;
+      if (len[(size_t)r] > rmax) rmax = len[(size_t)r];
+    }
+    nz = ai[(size_t)m];
+    /* MatMarkDiagonal_SeqAIJ aij.c:1506-1527 */
+    diag.assign((size_t)m, 0);
+    for (PetscInt r = 0; r < m; r++) {
+      diag[(size_t)r] = ai[(size_t)r + 1];
+      for (PetscInt k = ai[(size_t)r]; k < ai[(size_t)r + 1]; k++) if (j[(size_t)k] == r) { diag[(size_t)r] = k; break; }
+    }
+    /* MatCheckCompressedRow(ratio 0.6) compressedrow.c:45-72 */
+    const PetscInt zrows = m - nonzerorowcnt;
+    cprow_i.clear(); cprow_rindex.clear();
+    if (zrows < 0.6 * m) cprow_use = false;
+    else {
+      cprow_use = true;
+      cprow_i.push_back(0);
+      for (PetscInt r = 0; r < m; r++) {
+        if (ai[(size_t)r + 1] - ai[(size_t)r] == 0) continue;
+        cprow_i.push_back(ai[(size_t)r + 1]);
+        cprow_rindex.push_back(r);
+      }
+    }
+    assembled = true;
+  }
+  /* adopt caller CSR (MatCreateSeqAIJWithArrays) */
+  void adopt(PetscInt m_, PetscInt n_, const PetscInt *ii, const PetscInt *jj, const double *aa)
+  {
+    m = m_; n = n_;
+    const int64_t tot = ii[m];
+    start.assign((size_t)m + 1, 0); len.assign((size_t)m, 0); cap.assign((size_t)m, 0);
+    for (PetscInt r = 0; r < m; r++) { start[(size_t)r] = ii[r]; len[(size_t)r] = cap[(size_t)r] = ii[r + 1] - ii[r]; }
+    start[(size_t)m] = tot;
+    j.assign(jj, jj + tot); a.assign(aa, aa + tot);
+    relocated = false; nonzerostate++; values_dirty = true;
+  }
+  PetscErrorCode upload(phip_ctx ctx)
+  {
+    if (dev && dev_nonzerostate == nonzerostate) {
+      if (values_dirty) CHKPHIP(phip_mat_update_values(dev, a.data()));
+    } else {
+      if (dev) { CHKPHIP(phip_mat_destroy(dev)); dev = NULL; }
+      CHKPHIP(phip_mat_create(ctx, m, n, ai.data(), j.data(), a.data(), cprow_use ? 1 : 0, (PetscInt)cprow_rindex.size(),
+                              cprow_use ? cprow_i.data() : NULL, cprow_use ? cprow_rindex.data() : NULL, &dev));
+      dev_nonzerostate = nonzerostate;
+    }
+    values_dirty = false;
+    return 0;
+  }
+  void destroy() { if (dev) phip_mat_destroy(dev); dev = NULL; }
+};
+
+/* ================================================================================================ */
+/* Mat                                                                                              */
+struct _MatOps { /* the _MatOps slots (include/petsc/private/matimpl.h:28-206) this slice fills */
+  PetscErrorCode (*setvalues)(Mat, PetscInt, const PetscInt[], PetscInt, const PetscInt[], const PetscScalar[], InsertMode);
+  PetscErrorCode (*mult)(Mat, Vec, Vec);
+  PetscErrorCode (*multadd)(Mat, Vec, Vec, Vec);
+  PetscErrorCode (*getdiagonal)(Mat, Vec);
+  PetscErrorCode (*assemblyend)(Mat, MatAssemblyType);
+  PetscErrorCode (*zeroentries)(Mat);
+  PetscErrorCode (*getvecs)(Mat, Vec *, Vec *);
+  PetscErrorCode (*destroy)(Mat);
+};
+
+struct StashEntry { PetscInt row, col; double v; };
+
+struct _p_Mat {
+  PetscComm   comm;
+  std::string type;
+  PetscInt    m, n, M, N;
+  std::vector<PetscInt> rrange, crange;
+  bool        type_set, preallocated, assembled, was_assembled;
+  uint64_t    state;
+  _MatOps     ops;
+  /* Mat_SeqAIJ / Mat_MPIAIJ (mpiaij.h:36-79): A = diagonal block (or the whole Seq matrix), B = off-diagonal block */
+  HostAIJ     A, B;
+  std::vector<PetscInt> garray;
+  std::vector<PetscInt> to_procs, to_starts, to_indices, from_procs, from_starts;
+  double     *lvec;
+  phip_halo   halo;
+  std::vector<StashEntry> stash; int stash_mode;
+  bool        mpi;
+};
+
+static std::map<std::string, PetscErrorCode (*)(Mat)> &MatList()
+{
+  static std::map<std::string, PetscErrorCode (*)(Mat)> l;
+  return l;
+}
+extern "C" PetscErrorCode MatRegister(const char *sname, PetscErrorCode (*ctor)(Mat))
+{
+  if (!sname || !ctor) SETERRQ(PETSC_ERR_ARG_NULL, "MatRegister: null argument");
+  MatList()[sname] = ctor;
+  return 0;
+}
+
+#define MCTX(A) ((A)->comm->ctx)
+#define MatCheck(A, name) do { if (!(A)) SETERRQ(PETSC_ERR_ARG_NULL, name ": null matrix"); if (!(A)->type_set) SETERRQ(PETSC_ERR_ARG_TYPENOTSET, name ": matrix type not set"); } while (0)
+#define MatCheckAssembled(A, name) do { MatCheck(A, name); if (!(A)->assembled) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Not for unassembled matrix"); } while (0)
+
+extern "C" PetscErrorCode MatCreate(PetscComm comm, Mat *A)
+{
+  if (!comm || !A) SETERRQ(PETSC_ERR_ARG_NULL, "MatCreate: null argument");
+  Mat B = new _p_Mat();
+  B->comm = comm; B->m = B->n = B->M = B->N = PETSC_DECIDE;
+  B->type_set = B->preallocated = B->assembled = B->was_assembled = false; B->state = 0;
+  memset(&B->ops, 0, sizeof(B->ops));
+  B->lvec = NULL; B->halo = NULL; B->stash_mode = 0; B->mpi = false;
+  *A = B;
+  return 0;
+}
+extern "C" PetscErrorCode MatSetSizes(Mat A, PetscInt m, PetscInt n, PetscInt M, PetscInt N)
+{
+  if (!A) SETERRQ(PETSC_ERR_ARG_NULL, "MatSetSizes: null matrix");
+  if (M > 0 && m > M) SETERRQ(PETSC_ERR_ARG_INCOMP, "Local column size %d cannot be larger than global column size %d", m, M); /* gcreate.c:152 */
+  if (N > 0 && n > N) SETERRQ(PETSC_ERR_ARG_INCOMP, "Local row size %d cannot be larger than global row size %d", n, N);
+  if (A->type_set && A->preallocated) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Cannot change/reset matrix sizes after preallocation");
+  A->m = m; A->n = n; A->M = M; A->N = N;
+  return 0;
+}
+static PetscErrorCode mat_layouts(Mat A)
+{
+  if (!A->rrange.empty()) return 0;
+  PetscErrorCode ierr = layout_setup(A->comm, &A->m, &A->M, A->rrange); CHKERRQ(ierr);
+  ierr = layout_setup(A->comm, &A->n, &A->N, A->crange); CHKERRQ(ierr);
+  return 0;
+}
+
+/* ---- SeqAIJHIP ---- */
+static PetscErrorCode MatSetValues_SeqAIJHIP(Mat A, PetscInt m, const PetscInt im[], PetscInt n, const PetscInt in[], const PetscScalar v[], InsertMode mode)
+{
+  for (PetscInt k = 0; k < m; k++) {
+    const PetscInt row = im[k];
+    if (row < 0) continue;
+    if (row >= A->m) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Row too large: row %d max %d", row, A->m - 1);
+    for (PetscInt l = 0; l < n; l++) {
+      if (in[l] < 0) continue;
+      if (in[l] >= A->n) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Column too large: col %d max %d", in[l], A->n - 1);
+      A->A.set(row, in[l], v[l + k * n], mode == ADD_VALUES);
+    }
+  }
+  return 0;
+}
+static PetscErrorCode MatAssemblyEnd_SeqAIJHIP(Mat A, MatAssemblyType type)
+{
+  if (type == MAT_FLUSH_ASSEMBLY) return 0;
+  A->A.assembly_end();
+  return A->A.upload(MCTX(A)); /* precedent MatAssemblyEnd_SeqAIJCUSP aijcusp.cu:451-462: CPU assemble, then copy to the GPU */
+}
+static PetscErrorCode MatMult_SeqAIJHIP(Mat A, Vec x, Vec y) { CHKPHIP(phip_mat_mult(A->A.dev, x->d, y->d)); return 0; }
+static PetscErrorCode MatMultAdd_SeqAIJHIP(Mat A, Vec x, Vec y, Vec z) { CHKPHIP(phip_mat_multadd(A->A.dev, x->d, y->d, z->d)); return 0; }
+static PetscErrorCode MatGetDiagonal_SeqAIJHIP(Mat A, Vec v) { CHKPHIP(phip_mat_getdiagonal(A->A.dev, v->d)); return 0; }
+static PetscErrorCode MatZeroEntries_AIJHIP(Mat A)
+{
+  std::fill(A->A.a.begin(), A->A.a.end(), 0.0); A->A.values_dirty = true;
+  std::fill(A->B.a.begin(), A->B.a.end(), 0.0); A->B.values_dirty = true;
+  return 0;
+}
+static PetscErrorCode MatCreateVecs_AIJHIP(Mat A, Vec *right, Vec *left) /* MatCreateVecs_SeqAIJCUSP aijcusp.cu:287-309 */
+{
+  PetscErrorCode ierr;
+  if (right) {
+    ierr = VecCreate(A->comm, right); CHKERRQ(ierr);
+    ierr = VecSetSizes(*right, A->n, A->N); CHKERRQ(ierr);
+    ierr = VecSetType(*right, VECHIP); CHKERRQ(ierr);
+  }
+  if (left) {
+    ierr = VecCreate(A->comm, left); CHKERRQ(ierr);
+    ierr = VecSetSizes(*left, A->m, A->M); CHKERRQ(ierr);
+    ierr = VecSetType(*left, VECHIP); CHKERRQ(ierr);
+  }
+  return 0;
+}
+static PetscErrorCode MatDestroy_AIJHIP(Mat A)
+{
+  A->A.destroy(); A->B.destroy();
+  if (A->halo) phip_halo_destroy(A->halo);
+  if (A->lvec) phip_free(MCTX(A), A->lvec);
+  A->halo = NULL; A->lvec = NULL;
+  return 0;
+}
+/* MatCreate_SeqAIJCUSP aijcusp.cu:565-598 is the recipe: host AIJ + overridden mult/multadd/assemblyend/destroy/getvecs */
+static PetscErrorCode MatCreate_SeqAIJHIP(Mat A)
+{
+  if (A->comm->size > 1) SETERRQ(PETSC_ERR_ARG_WRONG, "Comm must be of size 1"); /* aij.c:3937 */
+  PetscErrorCode ierr = mat_layouts(A); CHKERRQ(ierr);
+  A->ops.setvalues = MatSetValues_SeqAIJHIP; A->ops.mult = MatMult_SeqAIJHIP; A->ops.multadd = MatMultAdd_SeqAIJHIP;
+  A->ops.getdiagonal = MatGetDiagonal_SeqAIJHIP; A->ops.assemblyend = MatAssemblyEnd_SeqAIJHIP; A->ops.zeroentries = MatZeroEntries_AIJHIP;
+  A->ops.getvecs = MatCreateVecs_AIJHIP; A->ops.destroy = MatDestroy_AIJHIP;
+  A->type = MATSEQAIJHIP; A->type_set = true; A->mpi = false;
+  return 0;
+}
+
+/* ---- MPIAIJHIP ---- */
+/* MatSetValues_MPIAIJ mpiaij.c:528-632: local rows: column in [cstart,cend) -> A with local column; otherwise -> B with the GLOBAL
+   column before the first assembly (:614) and the compact column afterwards (colmap lookup :588-613); other rows -> stash (:619-629) */
+static PetscErrorCode MatSetValues_MPIAIJHIP(Mat A, PetscInt m, const PetscInt im[], PetscInt n, const PetscInt in[], const PetscScalar v[], InsertMode mode)
+{
+  const PetscInt rstart = A->rrange[(size_t)A->comm->rank], rend = A->rrange[(size_t)A->comm->rank + 1];
+  const PetscInt cstart = A->crange[(size_t)A->comm->rank], cend = A->crange[(size_t)A->comm->rank + 1];
+  for (PetscInt i = 0; i < m; i++) {
+    if (im[i] < 0) continue;
+    if (im[i] >= A->M) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Row too large: row %d max %d", im[i], A->M - 1);
+    if (im[i] >= rstart && im[i] < rend) {
+      const PetscInt row = im[i] - rstart;
+      for (PetscInt jx = 0; jx < n; jx++) {
+        const double value = v[i * n + jx];
+        if (in[jx] >= cstart && in[jx] < cend) A->A.set(row, in[jx] - cstart, value, mode == ADD_VALUES);
+        else if (in[jx] < 0) continue;
+        else if (in[jx] >= A->N) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Column too large: col %d max %d", in[jx], A->N - 1);
+        else {
+          PetscInt col = in[jx];
+          if (A->was_assembled) {
+            auto it = std::lower_bound(A->garray.begin(), A->garray.end(), in[jx]);
+            if (it == A->garray.end() || *it != in[jx])
+              SETERRQ(PETSC_ERR_SUP, "Inserting a new off-process nonzero at global row/column (%d, %d) after the first assembly is not supported (the reference disassembles the matrix, mpiaij.c:598-599)", im[i], in[jx]);
+            col = (PetscInt)(it - A->garray.begin());
+          }
+          A->B.set(row, col, value, mode == ADD_VALUES);
+        }
+      }
+    } else {
+      if (A->stash_mode && A->stash_mode != (int)mode) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Cannot mix ADD_VALUES and INSERT_VALUES for off-process entries");
+      A->stash_mode = (int)mode;
+      for (PetscInt jx = 0; jx < n; jx++) {
+        if (in[jx] < 0) continue;
+        if (in[jx] >= A->N) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Column too large: col %d max %d", in[jx], A->N - 1);
+        A->stash.push_back({im[i], in[jx], v[i * n + jx]});
+      }
+    }
+  }
+  return 0;
+}
+
+/* drain the stash (MatAssemblyBegin/End_MPIAIJ mpiaij.c:680-737): entries travel to the owner of their row */
+static PetscErrorCode mat_stash_exchange(Mat A)
+{
+  const int size = A->comm->size, rank = A->comm->rank;
+  int32_t   mine[2] = {(int32_t)A->stash.size(), A->stash_mode};
+  std::vector<int32_t> all((size_t)2 * size);
+  CHKPHIP(phip_comm_allgather_host(A->comm->comm, mine, all.data(), sizeof(mine)));
+  bool any = false; int mode = 0;
+  for (int r = 0; r < size; r++) { if (all[(size_t)2 * r]) any = true; if (all[(size_t)2 * r + 1]) { if (mode && mode != all[(size_t)2 * r + 1]) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Some processors inserted others added"); mode = all[(size_t)2 * r + 1]; } }
+  if (!any) return 0;
+  std::vector<int32_t> scount((size_t)size, 0), rcount((size_t)size, 0);
+  std::vector<int> owner(A->stash.size());
+  for (size_t k = 0; k < A->stash.size(); k++) {
+    const int o = (int)(std::upper_bound(A->rrange.begin(), A->rrange.end(), A->stash[k].row) - A->rrange.begin()) - 1;
+    owner[k] = o; scount[(size_t)o] += 4; /* row, col, value as two int32 words */
+  }
+  std::vector<int32_t> cm((size_t)size * size);
+  CHKPHIP(phip_comm_allgather_host(A->comm->comm, scount.data(), cm.data(), sizeof(int32_t) * (size_t)size));
+  for (int p = 0; p < size; p++) rcount[(size_t)p] = cm[(size_t)p * size + rank];
+  std::vector<size_t> off((size_t)size + 1, 0);
+  for (int p = 0; p < size; p++) off[(size_t)p + 1] = off[(size_t)p] + (size_t)scount[(size_t)p];
+  std::vector<int32_t> sbuf(off[(size_t)size] + 1), fill((size_t)size, 0);
+  for (size_t k = 0; k < A->stash.size(); k++) {
+    int32_t *w = sbuf.data() + off[(size_t)owner[k]] + fill[(size_t)owner[k]];
+    w[0] = A->stash[k].row; w[1] = A->stash[k].col; memcpy(w + 2, &A->stash[k].v, sizeof(double));
+    fill[(size_t)owner[k]] += 4;
+  }
+  size_t rtot = 0;
+  for (int p = 0; p < size; p++) rtot += (size_t)rcount[(size_t)p];
+  std::vector<int32_t> rbuf(rtot + 1);
+  CHKPHIP(phip_comm_alltoallv_i32(A->comm->comm, sbuf.data(), scount.data(), rbuf.data(), rcount.data()));
+  A->stash.clear(); A->stash_mode = 0;
+  for (size_t k = 0; k + 3 < rtot + 1 && k < rtot; k += 4) {
+    PetscInt row = rbuf[k], col = rbuf[k + 1]; double val; memcpy(&val, &rbuf[k + 2], sizeof(double));
+    PetscErrorCode ierr = MatSetValues_MPIAIJHIP(A, 1, &row, 1, &col, &val, (InsertMode)mode); CHKERRQ(ierr);
+  }
+  return 0;
+}
+
+/* MatSetUpMultiply_MPIAIJ mmaij.c:69-129 + VecScatterCreate_PtoS vpscat.c:2297-2495 */
+static PetscErrorCode MatSetUpMultiply_MPIAIJHIP(Mat A)
+{
+  const int size = A->comm->size, rank = A->comm->rank;
+  HostAIJ  &B = A->B;
+  /* mark the global columns B uses; garray = those columns ascending; rewrite B's columns to the compact ids (mmaij.c:71-96) */
+  std::vector<PetscInt> indices((size_t)A->N + 1, 0);
+  for (PetscInt r = 0; r < B.m; r++)
+    for (PetscInt k = 0; k < B.len[(size_t)r]; k++) indices[(size_t)B.j[(size_t)B.start[(size_t)r] + (size_t)k]] = 1;
+  A->garray.clear();
+  for (PetscInt c = 0; c < A->N; c++) if (indices[(size_t)c]) A->garray.push_back(c);
+  const PetscInt ec = (PetscInt)A->garray.size();
+  for (PetscInt c = 0; c < ec; c++) indices[(size_t)A->garray[(size_t)c]] = c;
+  for (PetscInt r = 0; r < B.m; r++)
+    for (PetscInt k = 0; k < B.len[(size_t)r]; k++) { PetscInt &c = B.j[(size_t)B.start[(size_t)r] + (size_t)k]; c = indices[(size_t)c]; }
+  B.n = ec; /* aij->B->cmap->n = ec, mmaij.c:97 */
+  /* receive side (vpscat.c:2327-2340, 2423-2447): owner of every ghost, neighbours ascending, contiguous landing in lvec */
+  std::vector<int32_t> need((size_t)size, 0);
+  {
+    int jr = 0;
+    for (PetscInt k = 0; k < ec; k++) {
+      const PetscInt idx = A->garray[(size_t)k];
+      if (idx < A->crange[(size_t)jr]) jr = 0;
+      while (idx >= A->crange[(size_t)jr + 1]) jr++;
+      if (jr == rank) SETERRQ(PETSC_ERR_LIB, "MatSetUpMultiply: ghost column %d is locally owned", idx);
+      need[(size_t)jr]++;
+    }
+  }
+  A->from_procs.clear(); A->from_starts.assign(1, 0);
+  for (int p = 0; p < size; p++) if (need[(size_t)p]) { A->from_procs.push_back(p); A->from_starts.push_back(A->from_starts.back() + need[(size_t)p]); }
+  /* handshake (PetscGatherNumberOfMessages/MessageLengths + Isend/Irecv of the index lists, vpscat.c:2346-2392) */
+  std::vector<int32_t> cm((size_t)size * size), want((size_t)size, 0);
+  CHKPHIP(phip_comm_allgather_host(A->comm->comm, need.data(), cm.data(), sizeof(int32_t) * (size_t)size));
+  size_t wtot = 0;
+  for (int p = 0; p < size; p++) { want[(size_t)p] = cm[(size_t)p * size + rank]; wtot += (size_t)want[(size_t)p]; }
+  std::vector<int32_t> rbuf(wtot + 1);
+  CHKPHIP(phip_comm_alltoallv_i32(A->comm->comm, A->garray.data(), need.data(), rbuf.data(), want.data()));
+  /* send side: neighbours ascending (PetscSortMPIIntWithArray :2348), indices = global - owners[rank] (:2416) */
+  A->to_procs.clear(); A->to_starts.assign(1, 0); A->to_indices.clear();
+  const PetscInt base = A->crange[(size_t)rank];
+  size_t pos = 0;
+  for (int p = 0; p < size; p++) {
+    if (!want[(size_t)p]) continue;
+    A->to_procs.push_back(p);
+    for (int32_t k = 0; k < want[(size_t)p]; k++) {
+      const PetscInt loc = rbuf[pos + (size_t)k] - base;
+      if (loc < 0 || loc >= A->n) SETERRQ(PETSC_ERR_LIB, "MatSetUpMultiply: rank %d asked for entry %d that rank %d does not own", p, rbuf[pos + (size_t)k], rank);
+      A->to_indices.push_back(loc);
+    }
+    pos += (size_t)want[(size_t)p];
+    A->to_starts.push_back((PetscInt)A->to_indices.size());
+  }
+  /* lvec (mmaij.c:104) on the device, and the device exchange plan */
+  if (A->lvec) { CHKPHIP(phip_free(MCTX(A), A->lvec)); A->lvec = NULL; }
+  CHKPHIP(phip_malloc(MCTX(A), sizeof(double) * (size_t)ec, (void **)&A->lvec));
+  if (A->halo) { CHKPHIP(phip_halo_destroy(A->halo)); A->halo = NULL; }
+  CHKPHIP(phip_halo_create(A->comm->comm, (PetscInt)A->to_procs.size(), A->to_procs.data(), A->to_starts.data(), A->to_indices.data(),
+                           (PetscInt)A->from_procs.size(), A->from_procs.data(), A->from_starts.data(), &A->halo));
+  return 0;
+}
+
+/* MatAssemblyEnd_MPIAIJ mpiaij.c:703-773 */
+static PetscErrorCode MatAssemblyEnd_MPIAIJHIP(Mat A, MatAssemblyType type)
+{
+  PetscErrorCode ierr = mat_stash_exchange(A); CHKERRQ(ierr);
+  if (type == MAT_FLUSH_ASSEMBLY) return 0;
+  A->A.assembly_end();
+  if (!A->was_assembled) { ierr = MatSetUpMultiply_MPIAIJHIP(A); CHKERRQ(ierr); } /* :753-755 */
+  A->B.assembly_end();
+  ierr = A->A.upload(MCTX(A)); CHKERRQ(ierr);
+  ierr = A->B.upload(MCTX(A)); CHKERRQ(ierr);
+  return 0;
+}
+/* MatMult_MPIAIJ mpiaij.c:984-998: ScatterBegin; A*x; ScatterEnd; y += B*lvec -- the exchange overlaps the diagonal block */
+static PetscErrorCode MatMult_MPIAIJHIP(Mat A, Vec x, Vec y)
+{
+  CHKPHIP(phip_halo_begin(A->halo, x->d, A->lvec));
+  CHKPHIP(phip_mat_mult(A->A.dev, x->d, y->d));
+  CHKPHIP(phip_halo_end(A->halo));
+  CHKPHIP(phip_mat_multadd(A->B.dev, A->lvec, y->d, y->d));
+  return 0;
+}
+/* MatMultAdd_MPIAIJ mpiaij.c:1014-1025 */
+static PetscErrorCode MatMultAdd_MPIAIJHIP(Mat A, Vec x, Vec y, Vec z)
+{
+  CHKPHIP(phip_halo_begin(A->halo, x->d, A->lvec));
+  CHKPHIP(phip_mat_multadd(A->A.dev, x->d, y->d, z->d));
+  CHKPHIP(phip_halo_end(A->halo));
+  CHKPHIP(phip_mat_multadd(A->B.dev, A->lvec, z->d, z->d));
+  return 0;
+}
+/* MatGetDiagonal_MPIAIJ mpiaij.c:1125-1135 */
+static PetscErrorCode MatGetDiagonal_MPIAIJHIP(Mat A, Vec v)
+{
+  if (A->M != A->N) SETERRQ(PETSC_ERR_SUP, "Supports only square matrix where A->A is diag block");
+  if (A->rrange[(size_t)A->comm->rank] != A->crange[(size_t)A->comm->rank] || A->m != A->n) SETERRQ(PETSC_ERR_ARG_SIZ, "row partition must equal col partition");
+  CHKPHIP(phip_mat_getdiagonal(A->A.dev, v->d));
+  return 0;
+}
+/* MatCreate_MPIAIJCUSP mpiaijcusp.cu:196-226 is the recipe: MPIAIJ whose A and B blocks are the GPU Seq type */
+static PetscErrorCode MatCreate_MPIAIJHIP(Mat A)
+{
+  PetscErrorCode ierr = mat_layouts(A); CHKERRQ(ierr);
+  A->ops.setvalues = MatSetValues_MPIAIJHIP; A->ops.mult = MatMult_MPIAIJHIP; A->ops.multadd = MatMultAdd_MPIAIJHIP;
+  A->ops.getdiagonal = MatGetDiagonal_MPIAIJHIP; A->ops.assemblyend = MatAssemblyEnd_MPIAIJHIP; A->ops.zeroentries = MatZeroEntries_AIJHIP;
+  A->ops.getvecs = MatCreateVecs_AIJHIP; A->ops.destroy = MatDestroy_AIJHIP;
+  A->type = MATMPIAIJHIP; A->type_set = true; A->mpi = true;
+  return 0;
+}
+static PetscErrorCode MatCreate_AIJHIP(Mat A) { return (A->comm->size == 1) ? MatCreate_SeqAIJHIP(A) : MatCreate_MPIAIJHIP(A); } /* matreg.c:47-57 */
+
+static void MatRegisterAll()
+{
+  static bool done = false;
+  if (done) return;
+  done = true;
+  MatRegister(MATSEQAIJHIP, MatCreate_SeqAIJHIP);
+  MatRegister(MATMPIAIJHIP, MatCreate_MPIAIJHIP);
+  MatRegister(MATAIJHIP, MatCreate_AIJHIP);
+}
+
+extern "C" PetscErrorCode MatSetType(Mat A, const char *type)
+{
+  if (!A || !type) SETERRQ(PETSC_ERR_ARG_NULL, "MatSetType: null argument");
+  MatRegisterAll();
+  auto it = MatList().find(type);
+  if (it == MatList().end()) SETERRQ(PETSC_ERR_ARG_UNKNOWN_TYPE, "Unknown Mat type given: %s", type); /* matreg.c:63 */
+  if (A->type_set) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "MatSetType: type already set to %s", A->type.c_str());
+  if ((A->m == PETSC_DECIDE && A->M == PETSC_DECIDE) || (A->n == PETSC_DECIDE && A->N == PETSC_DECIDE)) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Must call MatSetSizes() first");
+  return (*it->second)(A);
+}
+extern "C" PetscErrorCode MatGetType(Mat A, const char **type)
+{
+  if (!A || !type) SETERRQ(PETSC_ERR_ARG_NULL, "MatGetType: null argument");
+  *type = A->type.c_str();
+  return 0;
+}
+extern "C" PetscErrorCode MatSeqAIJSetPreallocation(Mat A, PetscInt nz, const PetscInt nnz[])
+{
+  MatCheck(A, "MatSeqAIJSetPreallocation");
+  if (A->mpi) return 0; /* PetscTryMethod: silently ignored for other types (aij.c:3538) */
+  if (nz == PETSC_DEFAULT || nz == PETSC_DECIDE) nz = 5; /* aij.c:3570 */
+  if (nz < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "nz cannot be less than 0: value %d", nz);
+  if (nnz) for (PetscInt r = 0; r < A->m; r++) {
+    if (nnz[r] < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "nnz cannot be less than 0: local row %d value %d", r, nnz[r]);
+    if (nnz[r] > A->n) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "nnz cannot be greater than row length: local row %d value %d rowlength %d", r, nnz[r], A->n);
+  }
+  A->A.prealloc(A->m, A->n, nz, nnz);
+  A->preallocated = true; A->assembled = false;
+  return 0;
+}
+/* MatMPIAIJSetPreallocation_MPIAIJ mpiaij.c:2793-2821: A is m x n(local), B is m x N until the first assembly */
+extern "C" PetscErrorCode MatMPIAIJSetPreallocation(Mat A, PetscInt d_nz, const PetscInt d_nnz[], PetscInt o_nz, const PetscInt o_nnz[])
+{
+  MatCheck(A, "MatMPIAIJSetPreallocation");
+  if (!A->mpi) return 0;
+  if (d_nz == PETSC_DEFAULT || d_nz == PETSC_DECIDE) d_nz = 5;
+  if (o_nz == PETSC_DEFAULT || o_nz == PETSC_DECIDE) o_nz = 2;
+  if (d_nz < 0 || o_nz < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "d_nz/o_nz cannot be less than 0: values %d %d", d_nz, o_nz);
+  A->A.prealloc(A->m, A->n, d_nz, d_nnz);
+  A->B.prealloc(A->m, A->N, o_nz, o_nnz);
+  A->garray.clear(); A->was_assembled = false;
+  A->preallocated = true; A->assembled = false;
+  return 0;
+}
+extern "C" PetscErrorCode MatSetUp(Mat A)
+{
+  MatCheck(A, "MatSetUp");
+  if (A->preallocated) return 0;
+  return A->mpi ? MatMPIAIJSetPreallocation(A, PETSC_DEFAULT, NULL, PETSC_DEFAULT, NULL) : MatSeqAIJSetPreallocation(A, PETSC_DEFAULT, NULL);
+}
+extern "C" PetscErrorCode MatSetValues(Mat A, PetscInt m, const PetscInt idxm[], PetscInt n, const PetscInt idxn[], const PetscScalar v[], InsertMode addv)
+{
+  MatCheck(A, "MatSetValues");
+  if (!m || !n) return 0;
+  if (!A->preallocated) { PetscErrorCode ierr = MatSetUp(A); CHKERRQ(ierr); }
+  if (addv != INSERT_VALUES && addv != ADD_VALUES) SETERRQ(PETSC_ERR_ARG_WRONG, "MatSetValues: InsertMode must be INSERT_VALUES or ADD_VALUES");
+  A->assembled = false; /* matrix.c:1183 */
+  return (*A->ops.setvalues)(A, m, idxm, n, idxn, v, addv);
+}
+extern "C" PetscErrorCode MatAssemblyBegin(Mat A, MatAssemblyType type) { MatCheck(A, "MatAssemblyBegin"); (void)type; return 0; }
+extern "C" PetscErrorCode MatAssemblyEnd(Mat A, MatAssemblyType type)
+{
+  MatCheck(A, "MatAssemblyEnd");
+  if (!A->preallocated) { PetscErrorCode ierr = MatSetUp(A); CHKERRQ(ierr); }
+  PetscErrorCode ierr = (*A->ops.assemblyend)(A, type); CHKERRQ(ierr);
+  if (type == MAT_FINAL_ASSEMBLY) { A->assembled = true; A->was_assembled = true; A->state++; } /* matrix.c:5111 */
+  return 0;
+}
+extern "C" PetscErrorCode MatZeroEntries(Mat A)
+{
+  MatCheck(A, "MatZeroEntries");
+  PetscErrorCode ierr = (*A->ops.zeroentries)(A); CHKERRQ(ierr);
+  if (A->assembled) { ierr = A->A.upload(MCTX(A)); CHKERRQ(ierr); if (A->mpi) { ierr = A->B.upload(MCTX(A)); CHKERRQ(ierr); } }
+  A->state++;
+  return 0;
+}
+extern "C" PetscErrorCode MatZeroRows(Mat A, PetscInt numRows, const PetscInt rows[], PetscScalar diagv, Vec x, Vec b)
+{
+  MatCheckAssembled(A, "MatZeroRows");
+  if (x || b) SETERRQ(PETSC_ERR_SUP, "MatZeroRows: fixing the right-hand side (x, b non-NULL) is not supported");
+  const PetscInt rstart = A->rrange[(size_t)A->comm->rank], rend = A->rrange[(size_t)A->comm->rank + 1];
+  for (PetscInt k = 0; k < numRows; k++) {
+    if (rows[k] < 0 || rows[k] >= A->M) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Row %d out of range", rows[k]);
+    if (rows[k] < rstart || rows[k] >= rend) SETERRQ(PETSC_ERR_SUP, "MatZeroRows: row %d is owned by another process", rows[k]);
+    const PetscInt r = rows[k] - rstart;
+    HostAIJ *blocks[2] = {&A->A, &A->B};
+    for (int w = 0; w < (A->mpi ? 2 : 1); w++)
+      for (PetscInt q = 0; q < blocks[w]->len[(size_t)r]; q++) blocks[w]->a[(size_t)blocks[w]->start[(size_t)r] + (size_t)q] = 0.0;
+    if (diagv != 0.0) {
+      if (A->A.diag[(size_t)r] >= A->A.ai[(size_t)r + 1]) SETERRQ(PETSC_ERR_SUP, "MatZeroRows: row %d has no diagonal entry to set", rows[k]);
+      A->A.a[(size_t)A->A.diag[(size_t)r]] = diagv;
+    }
+  }
+  A->A.values_dirty = true; A->B.values_dirty = true;
+  PetscErrorCode ierr = A->A.upload(MCTX(A)); CHKERRQ(ierr);
+  if (A->mpi) { ierr = A->B.upload(MCTX(A)); CHKERRQ(ierr); }
+  A->state++;
+  return 0;
+}
+
+extern "C" PetscErrorCode MatCreateSeqAIJWithArrays(PetscComm comm, PetscInt m, PetscInt n, PetscInt i[], PetscInt j[], PetscScalar a[], Mat *A)
+{
+  if (!i || !A) SETERRQ(PETSC_ERR_ARG_NULL, "MatCreateSeqAIJWithArrays: null argument");
+  if (i[0]) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "i (row indices) must start with 0"); /* aij.c:4040 */
+  PetscErrorCode ierr = MatCreate(comm, A); CHKERRQ(ierr);
+  ierr = MatSetSizes(*A, m, n, m, n); CHKERRQ(ierr);
+  ierr = MatSetType(*A, MATSEQAIJHIP); CHKERRQ(ierr);
+  for (PetscInt r = 0; r < m; r++) {
+    if (i[r + 1] < i[r]) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Negative row length in i (row indices) row = %d length = %d", r, i[r + 1] - i[r]);
+    for (PetscInt k = i[r]; k < i[r + 1]; k++) {
+      if (j[k] < 0 || j[k] >= n) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Column %d out of range in row %d", j[k], r);
+      if (k > i[r] && j[k] <= j[k - 1]) SETERRQ(PETSC_ERR_ARG_WRONG, "Column indices of row %d are not sorted and unique", r);
+    }
+  }
+  (*A)->A.adopt(m, n, i, j, a);
+  (*A)->preallocated = true;
+  ierr = MatAssemblyBegin(*A, MAT_FINAL_ASSEMBLY); CHKERRQ(ierr);
+  return MatAssemblyEnd(*A, MAT_FINAL_ASSEMBLY);
+}
+
+/* MatCreateMPIAIJWithArrays mpiaij.c:3647-3667 -> MatMPIAIJSetPreallocationCSR_MPIAIJ :3326-3384: local rows, GLOBAL sorted columns */
+extern "C" PetscErrorCode MatCreateMPIAIJWithArrays(PetscComm comm, PetscInt m, PetscInt n, PetscInt M, PetscInt N, const PetscInt i[], const PetscInt j[], const PetscScalar a[], Mat *Aout)
+{
+  if (!i || !Aout) SETERRQ(PETSC_ERR_ARG_NULL, "MatCreateMPIAIJWithArrays: null argument");
+  if (i[0]) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "i (row indices) must start with 0");
+  if (m < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "local number of rows (m) cannot be PETSC_DECIDE, or negative");
+  PetscErrorCode ierr = MatCreate(comm, Aout); CHKERRQ(ierr);
+  Mat A = *Aout;
+  ierr = MatSetSizes(A, m, n, M, N); CHKERRQ(ierr);
+  ierr = MatSetType(A, MATMPIAIJHIP); CHKERRQ(ierr);
+  const PetscInt cstart = A->crange[(size_t)comm->rank], cend = A->crange[(size_t)comm->rank + 1];
+  std::vector<PetscInt> dn((size_t)m), on((size_t)m);
+  for (PetscInt r = 0; r < m; r++) {
+    PetscInt d = 0;
+    for (PetscInt k = i[r]; k < i[r + 1]; k++) {
+      if (j[k] < 0 || j[k] >= A->N) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Column %d out of range in local row %d", j[k], r);
+      if (k > i[r] && j[k] <= j[k - 1]) SETERRQ(PETSC_ERR_ARG_WRONG, "Column indices of local row %d are not sorted and unique", r);
+      d += (j[k] >= cstart && j[k] < cend);
+    }
+    dn[(size_t)r] = d; on[(size_t)r] = i[r + 1] - i[r] - d;
+  }
+  ierr = MatMPIAIJSetPreallocation(A, 0, dn.data(), 0, on.data()); CHKERRQ(ierr);
+  /* sorted rows: append directly (same result as row-by-row MatSetValues_MPIAIJ, mpiaij.c:3371-3378) */
+  for (PetscInt r = 0; r < m; r++) {
+    size_t pa = (size_t)A->A.start[(size_t)r], pb = (size_t)A->B.start[(size_t)r];
+    for (PetscInt k = i[r]; k < i[r + 1]; k++) {
+      if (j[k] >= cstart && j[k] < cend) { A->A.j[pa] = j[k] - cstart; A->A.a[pa++] = a[k]; }
+      else { A->B.j[pb] = j[k]; A->B.a[pb++] = a[k]; }
+    }
+    A->A.len[(size_t)r] = dn[(size_t)r]; A->B.len[(size_t)r] = on[(size_t)r];
+  }
+  A->A.nonzerostate++; A->B.nonzerostate++;
+  ierr = MatAssemblyBegin(A, MAT_FINAL_ASSEMBLY); CHKERRQ(ierr);
+  return MatAssemblyEnd(A, MAT_FINAL_ASSEMBLY);
+}
+
+extern "C" PetscErrorCode MatGetSize(Mat A, PetscInt *M, PetscInt *N) { MatCheck(A, "MatGetSize"); if (M) *M = A->M; if (N) *N = A->N; return 0; }
+extern "C" PetscErrorCode MatGetLocalSize(Mat A, PetscInt *m, PetscInt *n) { MatCheck(A, "MatGetLocalSize"); if (m) *m = A->m; if (n) *n = A->n; return 0; }
+extern "C" PetscErrorCode MatGetOwnershipRange(Mat A, PetscInt *rstart, PetscInt *rend)
+{
+  MatCheck(A, "MatGetOwnershipRange");
+  if (rstart) *rstart = A->rrange[(size_t)A->comm->rank];
+  if (rend) *rend = A->rrange[(size_t)A->comm->rank + 1];
+  return 0;
+}
+extern "C" PetscErrorCode MatCreateVecs(Mat A, Vec *right, Vec *left) { MatCheck(A, "MatCreateVecs"); return (*A->ops.getvecs)(A, right, left); }
+
+/* MatMult matrix.c:2201-2230: checks, dispatch, and the output state bump the device op must do itself */
+extern "C" PetscErrorCode MatMult(Mat A, Vec x, Vec y)
+{
+  MatCheckAssembled(A, "MatMult"); VecCheckReady(x, "MatMult"); VecCheckReady(y, "MatMult");
+  if (x == y) SETERRQ(PETSC_ERR_ARG_IDN, "x and y must be different vectors");
+  if (A->N != x->N) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec x: global dim %d %d", A->N, x->N);
+  if (A->M != y->N) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec y: global dim %d %d", A->M, y->N);
+  if (A->m != y->n) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec y: local dim %d %d", A->m, y->n);
+  if (A->n != x->n) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec x: local dim %d %d", A->n, x->n);
+  PetscErrorCode ierr = (*A->ops.mult)(A, x, y); CHKERRQ(ierr);
+  y->state++;
+  return 0;
+}
+extern "C" PetscErrorCode MatMultAdd(Mat A, Vec v1, Vec v2, Vec v3) /* matrix.c:2346-2375 */
+{
+  MatCheckAssembled(A, "MatMultAdd"); VecCheckReady(v1, "MatMultAdd"); VecCheckReady(v2, "MatMultAdd"); VecCheckReady(v3, "MatMultAdd");
+  if (A->N != v1->N) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec v1: global dim %d %d", A->N, v1->N);
+  if (A->m != v3->n) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec v3: local dim %d %d", A->m, v3->n);
+  if (A->m != v2->n) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec v2: local dim %d %d", A->m, v2->n);
+  if (v1 == v3) SETERRQ(PETSC_ERR_ARG_IDN, "v1 and v3 must be different vectors");
+  PetscErrorCode ierr = (*A->ops.multadd)(A, v1, v2, v3); CHKERRQ(ierr);
+  v3->state++;
+  return 0;
+}
+extern "C" PetscErrorCode MatGetDiagonal(Mat A, Vec v)
+{
+  MatCheckAssembled(A, "MatGetDiagonal"); VecCheckReady(v, "MatGetDiagonal");
+  if (v->n != A->m) SETERRQ(PETSC_ERR_ARG_SIZ, "Nonconforming matrix and vector"); /* aij.c:1178 */
+  PetscErrorCode ierr = (*A->ops.getdiagonal)(A, v); CHKERRQ(ierr);
+  v->state++;
+  return 0;
+}
+/* MatGetRowMaxAbs_SeqAIJ aij.c:2755-2790 / _MPIAIJ mpiaij.c:2418-2460: set-up only, done on the host CSR */
+extern "C" PetscErrorCode MatGetRowMaxAbs(Mat A, Vec v, PetscInt idx[])
+{
+  MatCheckAssembled(A, "MatGetRowMaxAbs"); VecCheckReady(v, "MatGetRowMaxAbs");
+  if (idx) SETERRQ(PETSC_ERR_SUP, "MatGetRowMaxAbs: returning the column indices is not supported");
+  if (v->n != A->m) SETERRQ(PETSC_ERR_ARG_SIZ, "Nonconforming matrix and vector");
+  PetscScalar   *x;
+  PetscErrorCode ierr = VecGetArray(v, &x); CHKERRQ(ierr);
+  for (PetscInt r = 0; r < A->m; r++) {
+    double mx = 0.0;
+    for (PetscInt k = A->A.ai[(size_t)r]; k < A->A.ai[(size_t)r + 1]; k++) mx = std::max(mx, fabs(A->A.a[(size_t)k]));
+    if (A->mpi) for (PetscInt k = A->B.ai[(size_t)r]; k < A->B.ai[(size_t)r + 1]; k++) mx = std::max(mx, fabs(A->B.a[(size_t)k]));
+    x[r] = mx;
+  }
+  return VecRestoreArray(v, &x);
+}
+/* MatGetRowSum matrix.c:4445-4470: v = A * ones */
+extern "C" PetscErrorCode MatGetRowSum(Mat A, Vec v)
+{
+  MatCheckAssembled(A, "MatGetRowSum");
+  Vec            ones;
+  PetscErrorCode ierr = MatCreateVecs(A, &ones, NULL); CHKERRQ(ierr);
+  ierr = VecSet(ones, 1.0); CHKERRQ(ierr);
+  ierr = MatMult(A, ones, v); CHKERRQ(ierr);
+  return VecDestroy(&ones);
+}
+extern "C" PetscErrorCode MatDestroy(Mat *A)
+{
+  if (!A || !*A) return 0;
+  if ((*A)->ops.destroy) { PetscErrorCode ierr = (*(*A)->ops.destroy)(*A); CHKERRQ(ierr); }
+  delete *A;
+  *A = NULL;
+  return 0;
+}
+
+extern "C" PetscErrorCode MatHipGetBlockInfo(Mat A, int which, PetscInt *m, PetscInt *n, PetscInt *nz, PetscInt *nonzerorowcnt, PetscInt *rmax, PetscBool *cprow_use, PetscInt *cprow_nrows)
+{
+  MatCheckAssembled(A, "MatHipGetBlockInfo");
+  if (which == 1 && !A->mpi) SETERRQ(PETSC_ERR_ARG_WRONG, "MatHipGetBlockInfo: a Seq matrix has no off-diagonal block");
+  const HostAIJ &H = which ? A->B : A->A;
+  if (m) *m = H.m; if (n) *n = H.n; if (nz) *nz = H.nz; if (nonzerorowcnt) *nonzerorowcnt = H.nonzerorowcnt; if (rmax) *rmax = H.rmax;
+  if (cprow_use) *cprow_use = H.cprow_use ? PETSC_TRUE : PETSC_FALSE;
+  if (cprow_nrows) *cprow_nrows = (PetscInt)H.cprow_rindex.size();
+  return 0;
+}
+extern "C" PetscErrorCode MatHipGetBlockArrays(Mat A, int which, PetscInt *i, PetscInt *j, PetscScalar *a, PetscInt *diag, PetscInt *cprow_i, PetscInt *cprow_rindex)
+{
+  MatCheckAssembled(A, "MatHipGetBlockArrays");
+  if (which == 1 && !A->mpi) SETERRQ(PETSC_ERR_ARG_WRONG, "MatHipGetBlockArrays: a Seq matrix has no off-diagonal block");
+  const HostAIJ &H = which ? A->B : A->A;
+  if (i) memcpy(i, H.ai.data(), sizeof(PetscInt) * ((size_t)H.m + 1));
+  if (j) memcpy(j, H.j.data(), sizeof(PetscInt) * (size_t)H.nz);
+  if (a) memcpy(a, H.a.data(), sizeof(double) * (size_t)H.nz);
+  if (diag) memcpy(diag, H.diag.data(), sizeof(PetscInt) * (size_t)H.m);
+  if (H.cprow_use && cprow_i) memcpy(cprow_i, H.cprow_i.data(), sizeof(PetscInt) * H.cprow_i.size());
+  if (H.cprow_use && cprow_rindex) memcpy(cprow_rindex, H.cprow_rindex.data(), sizeof(PetscInt) * H.cprow_rindex.size());
+  return 0;
+}
+extern "C" PetscErrorCode MatHipGetGhostInfo(Mat A, PetscInt *ec, PetscInt *to_n, PetscInt *to_len, PetscInt *from_n)
+{
+  MatCheckAssembled(A, "MatHipGetGhostInfo");
+  if (!A->mpi) SETERRQ(PETSC_ERR_ARG_WRONG, "MatHipGetGhostInfo: not an MPIAIJHIP matrix");
+  if (ec) *ec = (PetscInt)A->garray.size();
+  if (to_n) *to_n = (PetscInt)A->to_procs.size();
+  if (to_len) *to_len = (PetscInt)A->to_indices.size();
+  if (from_n) *from_n = (PetscInt)A->from_procs.size();
+  return 0;
+}
+extern "C" PetscErrorCode MatHipGetGhostArrays(Mat A, PetscInt *garray, PetscInt *to_procs, PetscInt *to_starts, PetscInt *to_indices, PetscInt *from_procs, PetscInt *from_starts)
+{
+  MatCheckAssembled(A, "MatHipGetGhostArrays");
+  if (!A->mpi) SETERRQ(PETSC_ERR_ARG_WRONG, "MatHipGetGhostArrays: not an MPIAIJHIP matrix");
+  if (garray) memcpy(garray, A->garray.data(), sizeof(PetscInt) * A->garray.size());
+  if (to_procs) memcpy(to_procs, A->to_procs.data(), sizeof(PetscInt) * A->to_procs.size());
+  if (to_starts) memcpy(to_starts, A->to_starts.data(), sizeof(PetscInt) * A->to_starts.size());
+  if (to_indices) memcpy(to_indices, A->to_indices.data(), sizeof(PetscInt) * A->to_indices.size());
+  if (from_procs) memcpy(from_procs, A->from_procs.data(), sizeof(PetscInt) * A->from_procs.size());
+  if (from_starts) memcpy(from_starts, A->from_starts.data(), sizeof(PetscInt) * A->from_starts.size());
+  return 0;
+}
+
+/* ================================================================================================ */
+/* PetscBinary IO (big-endian; src/sys/fileio/sysio.c:217-300 byte-swaps on little-endian hosts)       */
+static inline uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+static inline uint64_t bswap64(uint64_t v) { return __builtin_bswap64(v); }
+static PetscErrorCode read_i32(FILE *f, PetscInt *out, size_t n)
+{
+  if (n && fread(out, sizeof(PetscInt), n, f) != n) SETERRQ(PETSC_ERR_FILE_READ, "Read past end of file");
+  for (size_t k = 0; k < n; k++) out[k] = (PetscInt)bswap32((uint32_t)out[k]);
+  return 0;
+}
+static PetscErrorCode read_f64(FILE *f, double *out, size_t n)
+{
+  if (n && fread(out, sizeof(double), n, f) != n) SETERRQ(PETSC_ERR_FILE_READ, "Read past end of file");
+  for (size_t k = 0; k < n; k++) { uint64_t u; memcpy(&u, &out[k], 8); u = bswap64(u); memcpy(&out[k], &u, 8); }
+  return 0;
+}
+static PetscErrorCode write_i32(FILE *f, const PetscInt *in, size_t n)
+{
+  std::vector<uint32_t> b(n);
+  for (size_t k = 0; k < n; k++) b[k] = bswap32((uint32_t)in[k]);
+  if (n && fwrite(b.data(), 4, n, f) != n) SETERRQ(PETSC_ERR_FILE_WRITE, "Error writing to file");
+  return 0;
+}
+static PetscErrorCode write_f64(FILE *f, const double *in, size_t n)
+{
+  std::vector<uint64_t> b(n);
+  for (size_t k = 0; k < n; k++) { uint64_t u; memcpy(&u, &in[k], 8); b[k] = bswap64(u); }
+  if (n && fwrite(b.data(), 8, n, f) != n) SETERRQ(PETSC_ERR_FILE_WRITE, "Error writing to file");
+  return 0;
+}
+
+/* MatLoad_SeqAIJ aij.c:4109-4177 / MatLoad_MPIAIJ mpiaij.c:2890-3089.  Same resulting matrix (row split m = M/size + ((M%size)>rank),
+   mpiaij.c:2929); every rank reads its own slab of the file instead of rank 0 shipping it. */
+extern "C" PetscErrorCode MatLoad(Mat A, const char *filename, int64_t *offset)
+{
+  if (!A || !filename) SETERRQ(PETSC_ERR_ARG_NULL, "MatLoad: null argument");
+  FILE *f = fopen(filename, "rb");
+  if (!f) SETERRQ(PETSC_ERR_FILE_OPEN, "Cannot open file %s for reading", filename);
+  const int64_t off0 = offset ? *offset : 0;
+  PetscInt      header[4];
+  PetscErrorCode ierr;
+  if (fseeko(f, (off_t)off0, SEEK_SET)) { fclose(f); SETERRQ(PETSC_ERR_FILE_READ, "Cannot seek in %s", filename); }
+  ierr = read_i32(f, header, 4); if (ierr) { fclose(f); return ierr; }
+  if (header[0] != MAT_FILE_CLASSID) { fclose(f); SETERRQ(PETSC_ERR_FILE_UNEXPECTED, "not matrix object"); }           /* aij.c:4134 */
+  const PetscInt M = header[1], N = header[2], nz = header[3];
+  if (nz < 0) { fclose(f); SETERRQ(PETSC_ERR_FILE_UNEXPECTED, "Matrix stored in special format on disk,cannot load as SeqAIJ"); } /* aij.c:4137 */
+  if (!A->type_set) {
+    if (A->M == PETSC_DECIDE && A->m == PETSC_DECIDE) { ierr = MatSetSizes(A, PETSC_DECIDE, PETSC_DECIDE, M, N); if (ierr) { fclose(f); return ierr; } }
+    ierr = MatSetType(A, MATAIJHIP); if (ierr) { fclose(f); return ierr; }
+  }
+  if (A->M != M || A->N != N) { fclose(f); SETERRQ(PETSC_ERR_FILE_UNEXPECTED, "Inconsistent # of rows/cols:Matrix in file is %d x %d, matrix has %d x %d", M, N, A->M, A->N); }
+  const PetscInt rstart = A->rrange[(size_t)A->comm->rank], rend = A->rrange[(size_t)A->comm->rank + 1], m = rend - rstart;
+  std::vector<PetscInt> rowlens((size_t)rend + 1);
+  ierr = read_i32(f, rowlens.data(), (size_t)rend); if (ierr) { fclose(f); return ierr; }
+  int64_t before = 0;
+  for (PetscInt r = 0; r < rstart; r++) before += rowlens[(size_t)r];
+  std::vector<PetscInt> li((size_t)m + 1, 0);
+  for (PetscInt r = 0; r < m; r++) li[(size_t)r + 1] = li[(size_t)r] + rowlens[(size_t)(rstart + r)];
+  const size_t lnz = (size_t)li[(size_t)m];
+  std::vector<PetscInt> lj(lnz + 1);
+  std::vector<double>   la(lnz + 1);
+  const int64_t cols0 = off0 + 16 + 4 * (int64_t)M, vals0 = cols0 + 4 * (int64_t)nz;
+  fseeko(f, (off_t)(cols0 + 4 * before), SEEK_SET);
+  ierr = read_i32(f, lj.data(), lnz); if (ierr) { fclose(f); return ierr; }
+  fseeko(f, (off_t)(vals0 + 8 * before), SEEK_SET);
+  ierr = read_f64(f, la.data(), lnz); if (ierr) { fclose(f); return ierr; }
+  fclose(f);
+  if (offset) *offset = vals0 + 8 * (int64_t)nz;
+  /* insert row by row (MatSetValues_SeqAIJ / _MPIAIJ, aij.c:4163-4171, mpiaij.c:3051): rows in the file need not be sorted */
+  std::vector<PetscInt> dn((size_t)m), on((size_t)m);
+  const PetscInt cstart = A->crange[(size_t)A->comm->rank], cend = A->crange[(size_t)A->comm->rank + 1];
+  for (PetscInt r = 0; r < m; r++) {
+    PetscInt d = 0;
+    for (PetscInt k = li[(size_t)r]; k < li[(size_t)r + 1]; k++) d += (lj[(size_t)k] >= cstart && lj[(size_t)k] < cend);
+    dn[(size_t)r] = A->mpi ? d : li[(size_t)r + 1] - li[(size_t)r]; on[(size_t)r] = li[(size_t)r + 1] - li[(size_t)r] - d;
+  }
+  if (A->mpi) { ierr = MatMPIAIJSetPreallocation(A, 0, dn.data(), 0, on.data()); CHKERRQ(ierr); }
+  else { ierr = MatSeqAIJSetPreallocation(A, 0, dn.data()); CHKERRQ(ierr); }
+  for (PetscInt r = 0; r < m; r++) {
+    const PetscInt grow = rstart + r;
+    ierr = MatSetValues(A, 1, &grow, li[(size_t)r + 1] - li[(size_t)r], lj.data() + li[(size_t)r], la.data() + li[(size_t)r], INSERT_VALUES); CHKERRQ(ierr);
+  }
+  ierr = MatAssemblyBegin(A, MAT_FINAL_ASSEMBLY); CHKERRQ(ierr);
+  return MatAssemblyEnd(A, MAT_FINAL_ASSEMBLY);
+}
+
+/* VecLoad_Binary src/vec/vec/utils/vecio.c:77-148 */
+extern "C" PetscErrorCode VecLoad(Vec v, const char *filename, int64_t *offset)
+{
+  if (!v || !filename) SETERRQ(PETSC_ERR_ARG_NULL, "VecLoad: null argument");
+  FILE *f = fopen(filename, "rb");
+  if (!f) SETERRQ(PETSC_ERR_FILE_OPEN, "Cannot open file %s for reading", filename);
+  const int64_t off0 = offset ? *offset : 0;
+  PetscInt      header[2];
+  fseeko(f, (off_t)off0, SEEK_SET);
+  PetscErrorCode ierr = read_i32(f, header, 2); if (ierr) { fclose(f); return ierr; }
+  if (header[0] != VEC_FILE_CLASSID) { fclose(f); SETERRQ(PETSC_ERR_ARG_WRONG, "Not a vector next in file"); }
+  const PetscInt N = header[1];
+  if (!v->setup) {
+    if (v->N == PETSC_DECIDE && v->n == PETSC_DECIDE) v->N = N;
+    ierr = VecSetType(v, VECHIP); if (ierr) { fclose(f); return ierr; }
+  }
+  if (v->N != N) { fclose(f); SETERRQ(PETSC_ERR_FILE_UNEXPECTED, "Vector in file different length (%d) then input vector (%d)", N, v->N); }
+  const PetscInt lo = v->range[(size_t)v->comm->rank];
+  PetscScalar   *a;
+  ierr = VecGetArray(v, &a); if (ierr) { fclose(f); return ierr; }
+  fseeko(f, (off_t)(off0 + 8 + 8 * (int64_t)lo), SEEK_SET);
+  ierr = read_f64(f, a, (size_t)v->n); fclose(f); CHKERRQ(ierr);
+  if (offset) *offset = off0 + 8 + 8 * (int64_t)N;
+  return VecRestoreArray(v, &a);
+}
+
+/* MatView_SeqAIJ_Binary aij.c:547-582 / MatView_MPIAIJ_Binary mpiaij.c:1180-1330: ranks append their parts in rank order */
+extern "C" PetscErrorCode MatView(Mat A, const char *filename, int append)
+{
+  MatCheckAssembled(A, "MatView");
+  const int size = A->comm->size, rank = A->comm->rank;
+  PetscInt  lnz = A->A.nz + (A->mpi ? A->B.nz : 0);
+  std::vector<PetscInt> all((size_t)size);
+  CHKPHIP(phip_comm_allgather_host(A->comm->comm, &lnz, all.data(), sizeof(PetscInt)));
+  int64_t nz = 0;
+  for (int r = 0; r < size; r++) nz += all[(size_t)r];
+  if (nz > 2147483647) SETERRQ(PETSC_ERR_SUP, "MatView: more than 2^31-1 nonzeros cannot be stored in the 32-bit PetscBinary header");
+  /* merged rows with global, ascending columns: B's columns left of the diagonal block, A, then the rest (MatGetRow_MPIAIJ order) */
+  const PetscInt cstart = A->crange[(size_t)rank];
+  std::vector<PetscInt> rl((size_t)A->m), cj((size_t)lnz + 1);
+  std::vector<double>   ca((size_t)lnz + 1);
+  size_t w = 0;
+  for (PetscInt r = 0; r < A->m; r++) {
+    const size_t w0 = w;
+    PetscInt kb = A->mpi ? A->B.ai[(size_t)r] : 0, kbe = A->mpi ? A->B.ai[(size_t)r + 1] : 0;
+    for (; kb < kbe && A->garray[(size_t)A->B.j[(size_t)kb]] < cstart; kb++) { cj[w] = A->garray[(size_t)A->B.j[(size_t)kb]]; ca[w++] = A->B.a[(size_t)kb]; }
+    for (PetscInt k = A->A.ai[(size_t)r]; k < A->A.ai[(size_t)r + 1]; k++) { cj[w] = A->A.j[(size_t)k] + cstart; ca[w++] = A->A.a[(size_t)k]; }
+    for (; kb < kbe; kb++) { cj[w] = A->garray[(size_t)A->B.j[(size_t)kb]]; ca[w++] = A->B.a[(size_t)kb]; }
+    rl[(size_t)r] = (PetscInt)(w - w0);
+  }
+  for (int phase = 0; phase < 3; phase++) {
+    for (int r = 0; r < size; r++) {
+      if (r == rank) {
+        FILE *f = fopen(filename, (phase == 0 && r == 0 && !append) ? "wb" : "ab");
+        if (!f) SETERRQ(PETSC_ERR_FILE_OPEN, "Cannot open file %s for writing", filename);
+        PetscErrorCode ierr = 0;
+        if (phase == 0) {
+          if (r == 0) { PetscInt header[4] = {MAT_FILE_CLASSID, A->M, A->N, (PetscInt)nz}; ierr = write_i32(f, header, 4); }
+          if (!ierr) ierr = write_i32(f, rl.data(), (size_t)A->m);
+        } else if (phase == 1) ierr = write_i32(f, cj.data(), (size_t)lnz);
+        else ierr = write_f64(f, ca.data(), (size_t)lnz);
+        fclose(f);
+        CHKERRQ(ierr);
+      }
+      CHKPHIP(phip_comm_barrier(A->comm->comm));
+    }
+  }
+  return 0;
+}
+extern "C" PetscErrorCode VecView(Vec v, const char *filename, int append)
+{
+  VecCheckReady(v, "VecView");
+  const PetscScalar *a;
+  PetscErrorCode     ierr = VecGetArrayRead(v, &a); CHKERRQ(ierr);
+  for (int r = 0; r < v->comm->size; r++) {
+    if (r == v->comm->rank) {
+      FILE *f = fopen(filename, (r == 0 && !append) ? "wb" : "ab");
+      if (!f) SETERRQ(PETSC_ERR_FILE_OPEN, "Cannot open file %s for writing", filename);
+      if (r == 0) { PetscInt header[2] = {VEC_FILE_CLASSID, v->N}; ierr = write_i32(f, header, 2); }
+      if (!ierr) ierr = write_f64(f, a, (size_t)v->n);
+      fclose(f);
+      CHKERRQ(ierr);
+    }
+    CHKPHIP(phip_comm_barrier(v->comm->comm));
+  }
+  return VecRestoreArrayRead(v, &a);
+}
+
+/* ================================================================================================ */
+/* PC: PCNONE and PCJACOBI (src/ksp/pc/impls/jacobi/jacobi.c)                                        */
+struct _p_PC {
+  PetscComm   comm;
+  std::string type;
+  Mat         mat, pmat;
+  Vec         diag, diagsqrt;
+  PCJacobiType jtype;
+  bool        useabs;
+  bool        setupcalled;
+  uint64_t    matstate;
+};
+extern "C" PetscErrorCode PCCreate(PetscComm comm, PC *pc)
+{
+  if (!comm || !pc) SETERRQ(PETSC_ERR_ARG_NULL, "PCCreate: null argument");
+  PC p = new _p_PC();
+  p->comm = comm; p->type = ""; p->mat = p->pmat = NULL; p->diag = p->diagsqrt = NULL; p->jtype = PC_JACOBI_DIAGONAL; p->useabs = false;
+  p->setupcalled = false; p->matstate = 0;
+  *pc = p;
+  return 0;
+}
+static PetscErrorCode PCReset_Jacobi(PC pc) /* jacobi.c:322-331 */
+{
+  PetscErrorCode ierr = VecDestroy(&pc->diag); CHKERRQ(ierr);
+  return VecDestroy(&pc->diagsqrt);
+}
+extern "C" PetscErrorCode PCSetType(PC pc, const char *type)
+{
+  if (!pc || !type) SETERRQ(PETSC_ERR_ARG_NULL, "PCSetType: null argument");
+  if (strcmp(type, PCNONE) && strcmp(type, PCJACOBI)) SETERRQ(PETSC_ERR_ARG_UNKNOWN_TYPE, "Unable to find requested PC type %s", type);
+  if (pc->type != type) { PetscErrorCode ierr = PCReset_Jacobi(pc); CHKERRQ(ierr); pc->setupcalled = false; }
+  pc->type = type;
+  return 0;
+}
+extern "C" PetscErrorCode PCSetOperators(PC pc, Mat Amat, Mat Pmat)
+{
+  if (!pc) SETERRQ(PETSC_ERR_ARG_NULL, "PCSetOperators: null PC");
+  if (pc->pmat != Pmat || pc->mat != Amat) { PetscErrorCode ierr = PCReset_Jacobi(pc); CHKERRQ(ierr); }
+  pc->mat = Amat; pc->pmat = Pmat; pc->setupcalled = false;
+  return 0;
+}
+extern "C" PetscErrorCode PCJacobiSetType(PC pc, PCJacobiType t) { if (!pc) SETERRQ(PETSC_ERR_ARG_NULL, "PCJacobiSetType: null PC"); pc->jtype = t; pc->setupcalled = false; return 0; }
+extern "C" PetscErrorCode PCJacobiSetUseAbs(PC pc, PetscBool flg) { if (!pc) SETERRQ(PETSC_ERR_ARG_NULL, "PCJacobiSetUseAbs: null PC"); pc->useabs = flg != 0; pc->setupcalled = false; return 0; }
+
+/* PCSetUp_Jacobi jacobi.c:140-219: fill whichever of diag / diagsqrt exists */
+static PetscErrorCode PCSetUp_Jacobi(PC pc)
+{
+  PetscErrorCode ierr;
+  Vec            targets[2] = {pc->diag, pc->diagsqrt};
+  for (int w = 0; w < 2; w++) {
+    Vec d = targets[w];
+    if (!d) continue;
+    if (pc->jtype == PC_JACOBI_ROWMAX) { ierr = MatGetRowMaxAbs(pc->pmat, d, NULL); CHKERRQ(ierr); }
+    else if (pc->jtype == PC_JACOBI_ROWSUM) { ierr = MatGetRowSum(pc->pmat, d); CHKERRQ(ierr); }
+    else { ierr = MatGetDiagonal(pc->pmat, d); CHKERRQ(ierr); }
+    /* VecReciprocal + the host loop :182-195 (or :204-212) as one device kernel */
+    CHKPHIP(phip_jacobi_setup(pc->comm->ctx, d->n, d->d, pc->useabs ? 1 : 0, w, NULL));
+    d->state++;
+  }
+  return 0;
+}
+extern "C" PetscErrorCode PCSetUp(PC pc)
+{
+  if (!pc) SETERRQ(PETSC_ERR_ARG_NULL, "PCSetUp: null PC");
+  if (pc->type.empty()) pc->type = PCJACOBI;
+  if (!pc->pmat) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Matrix must be set first"); /* precon.c:889 */
+  if (pc->setupcalled && pc->matstate == pc->pmat->state) return 0;
+  if (pc->type == PCJACOBI) { PetscErrorCode ierr = PCSetUp_Jacobi(pc); CHKERRQ(ierr); }
+  pc->setupcalled = true; pc->matstate = pc->pmat->state;
+  return 0;
+}
+extern "C" PetscErrorCode PCApply(PC pc, Vec x, Vec y)
+{
+  if (!pc) SETERRQ(PETSC_ERR_ARG_NULL, "PCApply: null PC");
+  if (x == y) SETERRQ(PETSC_ERR_ARG_IDN, "x and y must be different vectors"); /* precon.c:440 */
+  PetscErrorCode ierr = PCSetUp(pc); CHKERRQ(ierr);
+  if (pc->type == PCNONE) return VecCopy(x, y);
+  if (!pc->diag) { /* PCSetUp_Jacobi_NonSymmetric jacobi.c:253-263: lazily on first apply */
+    ierr = MatCreateVecs(pc->pmat, &pc->diag, NULL); CHKERRQ(ierr);
+    ierr = PCSetUp_Jacobi(pc); CHKERRQ(ierr);
+  }
+  return VecPointwiseMult(y, x, pc->diag); /* jacobi.c:288 */
+}
+static PetscErrorCode PCApplySymmetricLeftOrRight(PC pc, Vec x, Vec y)
+{
+  PetscErrorCode ierr = PCSetUp(pc); CHKERRQ(ierr);
+  if (pc->type == PCNONE) return VecCopy(x, y);
+  if (!pc->diagsqrt) { /* jacobi.c:231-241 */
+    ierr = MatCreateVecs(pc->pmat, &pc->diagsqrt, NULL); CHKERRQ(ierr);
+    ierr = PCSetUp_Jacobi(pc); CHKERRQ(ierr);
+  }
+  return VecPointwiseMult(y, x, pc->diagsqrt); /* jacobi.c:316 */
+}
+extern "C" PetscErrorCode PCApplySymmetricLeft(PC pc, Vec x, Vec y) { if (!pc) SETERRQ(PETSC_ERR_ARG_NULL, "null PC"); return PCApplySymmetricLeftOrRight(pc, x, y); }
+extern "C" PetscErrorCode PCApplySymmetricRight(PC pc, Vec x, Vec y) { if (!pc) SETERRQ(PETSC_ERR_ARG_NULL, "null PC"); return PCApplySymmetricLeftOrRight(pc, x, y); }
+extern "C" PetscErrorCode PCDestroy(PC *pc)
+{
+  if (!pc || !*pc) return 0;
+  PetscErrorCode ierr = PCReset_Jacobi(*pc); CHKERRQ(ierr);
+  delete *pc;
+  *pc = NULL;
+  return 0;
+}
+
+/* ================================================================================================ */
+/* KSP: the unmodified callers, restated op for op (cg.c:93-279, gmres.c:118-418, borthog2.c:36-111)   */
+struct _p_KSP {
+  PetscComm   comm;
+  std::string type;
+  PC          pc;
+  Mat         amat, pmat;
+  PetscReal   rtol, abstol, divtol, ttol, rnorm0, rnorm;
+  PetscInt    max_it, its;
+  bool        guess_zero, guess_zero_user;
+  KSPNormType normtype;
+  KSPConvergedReason reason;
+  std::vector<Vec> work;
+  Vec         vec_rhs, vec_sol;
+  /* residual history */
+  PetscReal  *hist; PetscInt hist_cap, hist_len; std::vector<PetscReal> hist_own;
+  /* CG */
+  bool        singlereduction;
+  /* GMRES (gmresimpl.h:11-46) */
+  PetscInt    max_k; KSPGMRESCGSRefinementType cgstype; PetscReal haptol;
+  std::vector<PetscScalar> hh, rs, cc, ss, orthogwork, nrs;
+  std::vector<Vec> vecs; PetscInt vv_allocated;
+  bool        setup;
+};
+extern "C" PetscErrorCode KSPCreate(PetscComm comm, KSP *ksp)
+{
+  if (!comm || !ksp) SETERRQ(PETSC_ERR_ARG_NULL, "KSPCreate: null argument");
+  KSP k = new _p_KSP();
+  k->comm = comm; k->type = KSPGMRES; /* default KSP type is GMRES (itcreate.c) */
+  k->pc = NULL; k->amat = k->pmat = NULL;
+  k->rtol = 1.e-5; k->abstol = 1.e-50; k->divtol = 1.e4; k->max_it = 10000; /* itcreate.c:706-714 */
+  k->ttol = 0; k->rnorm0 = 0; k->rnorm = 0; k->its = 0; k->guess_zero = k->guess_zero_user = true;
+  k->normtype = KSP_NORM_DEFAULT; k->reason = KSP_CONVERGED_ITERATING;
+  k->vec_rhs = k->vec_sol = NULL; k->hist = NULL; k->hist_cap = 0; k->hist_len = 0;
+  k->singlereduction = false;
+  k->max_k = 30; k->cgstype = KSP_GMRES_CGS_REFINE_NEVER; k->haptol = 1.0e-30; /* gmres.c:925-933 */
+  k->vv_allocated = 0; k->setup = false;
+  PetscErrorCode ierr = PCCreate(comm, &k->pc); CHKERRQ(ierr);
+  *ksp = k;
+  return 0;
+}
+static PetscErrorCode ksp_free_work(KSP k)
+{
+  for (auto &v : k->work) { PetscErrorCode ierr = VecDestroy(&v); CHKERRQ(ierr); }
+  k->work.clear();
+  for (auto &v : k->vecs) { PetscErrorCode ierr = VecDestroy(&v); CHKERRQ(ierr); }
+  k->vecs.clear(); k->vv_allocated = 0; k->setup = false;
+  return 0;
+}
+extern "C" PetscErrorCode KSPSetType(KSP k, const char *type)
+{
+  if (!k || !type) SETERRQ(PETSC_ERR_ARG_NULL, "KSPSetType: null argument");
+  if (strcmp(type, KSPCG) && strcmp(type, KSPGMRES)) SETERRQ(PETSC_ERR_ARG_UNKNOWN_TYPE, "Unable to find requested KSP type %s", type);
+  if (k->type != type) { PetscErrorCode ierr = ksp_free_work(k); CHKERRQ(ierr); }
+  k->type = type;
+  return 0;
+}
+extern "C" PetscErrorCode KSPSetOperators(KSP k, Mat Amat, Mat Pmat)
+{
+  if (!k) SETERRQ(PETSC_ERR_ARG_NULL, "KSPSetOperators: null KSP");
+  k->amat = Amat; k->pmat = Pmat;
+  return PCSetOperators(k->pc, Amat, Pmat);
+}
+extern "C" PetscErrorCode KSPGetPC(KSP k, PC *pc) { if (!k || !pc) SETERRQ(PETSC_ERR_ARG_NULL, "KSPGetPC: null argument"); *pc = k->pc; return 0; }
+extern "C" PetscErrorCode KSPSetTolerances(KSP k, PetscReal rtol, PetscReal abstol, PetscReal dtol, PetscInt maxits)
+{
+  if (!k) SETERRQ(PETSC_ERR_ARG_NULL, "KSPSetTolerances: null KSP");
+  if (rtol != PETSC_DEFAULT) { if (rtol < 0.0 || 1.0 <= rtol) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Relative tolerance %g must be non-negative and less than 1.0", rtol); k->rtol = rtol; }
+  if (abstol != PETSC_DEFAULT) { if (abstol < 0.0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Absolute tolerance %g must be non-negative", abstol); k->abstol = abstol; }
+  if (dtol != PETSC_DEFAULT) { if (dtol < 0.0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Divergence tolerance %g must be larger than 1.0", dtol); k->divtol = dtol; }
+  if (maxits != PETSC_DEFAULT) { if (maxits < 0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Maximum number of iterations %d must be non-negative", maxits); k->max_it = maxits; }
+  return 0;
+}
+extern "C" PetscErrorCode KSPSetInitialGuessNonzero(KSP k, PetscBool flg) { if (!k) SETERRQ(PETSC_ERR_ARG_NULL, "null KSP"); k->guess_zero_user = !flg; return 0; }
+extern "C" PetscErrorCode KSPSetNormType(KSP k, KSPNormType t) { if (!k) SETERRQ(PETSC_ERR_ARG_NULL, "null KSP"); k->normtype = t; return 0; }
+extern "C" PetscErrorCode KSPGMRESSetRestart(KSP k, PetscInt r)
+{
+  if (!k) SETERRQ(PETSC_ERR_ARG_NULL, "null KSP");
+  if (r < 1) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Restart must be positive"); /* gmres.c:736 */
+  if (r != k->max_k) { PetscErrorCode ierr = ksp_free_work(k); CHKERRQ(ierr); }
+  k->max_k = r;
+  return 0;
+}
+extern "C" PetscErrorCode KSPGMRESSetCGSRefinementType(KSP k, KSPGMRESCGSRefinementType t) { if (!k) SETERRQ(PETSC_ERR_ARG_NULL, "null KSP"); k->cgstype = t; return 0; }
+extern "C" PetscErrorCode KSPGMRESSetHapTol(KSP k, PetscReal tol) { if (!k) SETERRQ(PETSC_ERR_ARG_NULL, "null KSP"); if (tol < 0.0) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Tolerance must be non-negative"); k->haptol = tol; return 0; }
+extern "C" PetscErrorCode KSPCGSetSingleReduction(KSP k, PetscBool flg)
+{
+  if (!k) SETERRQ(PETSC_ERR_ARG_NULL, "null KSP");
+  if ((flg != 0) != k->singlereduction) { PetscErrorCode ierr = ksp_free_work(k); CHKERRQ(ierr); }
+  k->singlereduction = flg != 0;
+  return 0;
+}
+extern "C" PetscErrorCode KSPSetResidualHistory(KSP k, PetscReal a[], PetscInt na, PetscBool reset)
+{
+  if (!k) SETERRQ(PETSC_ERR_ARG_NULL, "null KSP");
+  (void)reset;
+  if (a) { k->hist = a; k->hist_cap = na; }
+  else { k->hist_own.assign((size_t)(na > 0 ? na : 10000), 0.0); k->hist = k->hist_own.data(); k->hist_cap = (PetscInt)k->hist_own.size(); }
+  k->hist_len = 0;
+  return 0;
+}
+extern "C" PetscErrorCode KSPGetResidualHistory(KSP k, PetscReal **a, PetscInt *na)
+{
+  if (!k) SETERRQ(PETSC_ERR_ARG_NULL, "null KSP");
+  if (a) *a = k->hist;
+  if (na) *na = k->hist_len;
+  return 0;
+}
+static inline void KSPLogResidualHistory(KSP k, PetscReal r) { if (k->hist && k->hist_len < k->hist_cap) k->hist[k->hist_len++] = r; }
+
+extern "C" PetscErrorCode KSPSetUp(KSP k)
+{
+  if (!k) SETERRQ(PETSC_ERR_ARG_NULL, "KSPSetUp: null KSP");
+  if (!k->amat) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "KSPSetUp: operators not set");
+  if (!k->vec_sol) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "KSPSetUp: solution vector not set (call through KSPSolve)");
+  PetscErrorCode ierr;
+  if (k->normtype == KSP_NORM_DEFAULT) k->normtype = KSP_NORM_PRECONDITIONED; /* CG cg.c:424, GMRES gmres.c:915: left PC, preconditioned norm */
+  if (k->pc->type.empty()) { ierr = PCSetType(k->pc, PCJACOBI); CHKERRQ(ierr); }
+  if (!k->setup) {
+    if (k->type == KSPCG) { /* KSPSetUp_CG cg.c:56-80: 3 work vectors (+2 for single reduction) */
+      const PetscInt nwork = k->singlereduction ? 5 : 3;
+      Vec           *w;
+      ierr = VecDuplicateVecs(k->vec_sol, nwork, &w); CHKERRQ(ierr);
+      k->work.assign(w, w + nwork);
+      free(w);
+    } else { /* KSPSetUp_GMRES gmres.c:39-97 */
+      const PetscInt mk = k->max_k;
+      k->hh.assign((size_t)(mk + 2) * (mk + 1), 0.0); k->rs.assign((size_t)mk + 2, 0.0);
+      k->cc.assign((size_t)mk + 1, 0.0); k->ss.assign((size_t)mk + 1, 0.0);
+      k->orthogwork.assign((size_t)mk + 2, 0.0); k->nrs.assign((size_t)mk + 2, 0.0);
+      k->vecs.assign((size_t)(2 + 2 + mk), NULL); /* VEC_OFFSET + 2 + max_k */
+      Vec *w;
+      ierr = VecDuplicateVecs(k->vec_sol, 5, &w); CHKERRQ(ierr); /* :85-95 */
+      for (int q = 0; q < 5 && q < (int)k->vecs.size(); q++) k->vecs[(size_t)q] = w[q];
+      for (int q = (int)k->vecs.size(); q < 5; q++) VecDestroy(&w[q]);
+      free(w);
+      k->vv_allocated = std::min<PetscInt>(5, (PetscInt)k->vecs.size());
+    }
+    k->setup = true;
+  }
+  return PCSetUp(k->pc); /* itfunc.c:332 */
+}
+
+/* KSPConvergedDefault iterativ.c:744-817 */
+static PetscErrorCode KSPConvergedDefault(KSP k, PetscInt n, PetscReal rnorm, KSPConvergedReason *reason)
+{
+  *reason = KSP_CONVERGED_ITERATING;
+  if (k->normtype == KSP_NORM_NONE) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Use KSPConvergedSkip() with KSPNormType of KSP_NORM_NONE");
+  if (!n) {
+    if (!k->guess_zero) { /* :761-788 */
+      PetscReal      snorm = 0;
+      PetscErrorCode ierr;
+      if (k->normtype == KSP_NORM_UNPRECONDITIONED) { ierr = VecNorm(k->vec_rhs, NORM_2, &snorm); CHKERRQ(ierr); }
+      else {
+        Vec z;
+        ierr = VecDuplicate(k->vec_rhs, &z); CHKERRQ(ierr);
+        ierr = PCApply(k->pc, k->vec_rhs, z); CHKERRQ(ierr);
+        if (k->normtype == KSP_NORM_PRECONDITIONED) { ierr = VecNorm(z, NORM_2, &snorm); CHKERRQ(ierr); }
+        else { PetscScalar nrm; ierr = VecDot(k->vec_rhs, z, &nrm); CHKERRQ(ierr); snorm = sqrt(fabs(nrm)); }
+        ierr = VecDestroy(&z); CHKERRQ(ierr);
+      }
+      if (!snorm) snorm = rnorm;
+      k->rnorm0 = snorm;
+    } else k->rnorm0 = rnorm;
+    k->ttol = std::max(k->rtol * k->rnorm0, k->abstol);
+  }
+  if (std::isnan(rnorm) || std::isinf(rnorm)) *reason = KSP_DIVERGED_NANORINF;
+  else if (rnorm <= k->ttol) *reason = (rnorm < k->abstol) ? KSP_CONVERGED_ATOL : KSP_CONVERGED_RTOL;
+  else if (rnorm >= k->divtol * k->rnorm0) *reason = KSP_DIVERGED_DTOL;
+  return 0;
+}
+#define KSPCheckDot(k, beta) do { if (std::isnan(beta) || std::isinf(beta)) { (k)->reason = KSP_DIVERGED_NANORINF; return 0; } } while (0) /* kspimpl.h:302-309 */
+
+/* KSPSolve_CG cg.c:93-279 */
+static PetscErrorCode KSPSolve_CG(KSP ksp)
+{
+  PetscErrorCode ierr;
+  PetscInt       i;
+  PetscScalar    dpi = 0.0, a = 1.0, beta = 0.0, betaold = 1.0, b = 0, delta = 0, dpiold;
+  PetscReal      dp = 0.0;
+  Vec            X = ksp->vec_sol, B = ksp->vec_rhs, R = ksp->work[0], Z = ksp->work[1], P = ksp->work[2], S, W;
+  Mat            Amat = ksp->amat;
+  const bool     sr = ksp->singlereduction;
+  if (sr) { S = ksp->work[3]; W = ksp->work[4]; } else { S = NULL; W = Z; }
+  ksp->its = 0;
+  if (!ksp->guess_zero) { ierr = MatMult(Amat, X, R); CHKERRQ(ierr); ierr = VecAYPX(R, -1.0, B); CHKERRQ(ierr); } /* :131-132 */
+  else { ierr = VecCopy(B, R); CHKERRQ(ierr); }                                                                  /* :134 */
+  switch (ksp->normtype) {
+  case KSP_NORM_PRECONDITIONED:
+    ierr = PCApply(ksp->pc, R, Z); CHKERRQ(ierr); ierr = VecNorm(Z, NORM_2, &dp); CHKERRQ(ierr); break;          /* :139-140 */
+  case KSP_NORM_UNPRECONDITIONED:
+    ierr = VecNorm(R, NORM_2, &dp); CHKERRQ(ierr); break;                                                        /* :143 */
+  case KSP_NORM_NATURAL:
+    ierr = PCApply(ksp->pc, R, Z); CHKERRQ(ierr);
+    if (sr) { ierr = MatMult(Amat, Z, S); CHKERRQ(ierr); ierr = VecTDot(Z, S, &delta); CHKERRQ(ierr); }
+    ierr = VecTDot(Z, R, &beta); CHKERRQ(ierr);
+    KSPCheckDot(ksp, beta);
+    dp = sqrt(fabs(beta)); break;                                                                                /* :146-153 */
+  case KSP_NORM_NONE: dp = 0.0; break;
+  default: SETERRQ(PETSC_ERR_SUP, "KSPSolve_CG: unsupported norm type %d", (int)ksp->normtype);
+  }
+  KSPLogResidualHistory(ksp, dp);
+  ksp->rnorm = dp;
+  ierr = KSPConvergedDefault(ksp, 0, dp, &ksp->reason); CHKERRQ(ierr);                                           /* :164 */
+  if (ksp->reason) return 0;
+  if (ksp->normtype != KSP_NORM_PRECONDITIONED && ksp->normtype != KSP_NORM_NATURAL) { ierr = PCApply(ksp->pc, R, Z); CHKERRQ(ierr); } /* :167-169 */
+  if (ksp->normtype != KSP_NORM_NATURAL) {
+    if (sr) { ierr = MatMult(Amat, Z, S); CHKERRQ(ierr); ierr = VecTDot(Z, S, &delta); CHKERRQ(ierr); }
+    ierr = VecTDot(Z, R, &beta); CHKERRQ(ierr);                                                                  /* :175 */
+    KSPCheckDot(ksp, beta);
+  }
+  i = 0;
+  do {
+    ksp->its = i + 1;
+    if (beta == 0.0) { ksp->reason = KSP_CONVERGED_ATOL; break; }                                                /* :182-185 */
+    else if ((i > 0) && (beta * betaold < 0.0)) { ksp->reason = KSP_DIVERGED_INDEFINITE_PC; break; }             /* :187-190 */
+    if (!i) { ierr = VecCopy(Z, P); CHKERRQ(ierr); b = 0.0; }                                                    /* :194 */
+    else { b = beta / betaold; ierr = VecAYPX(P, b, Z); CHKERRQ(ierr); }                                         /* :197,202 */
+    dpiold = dpi;
+    if (!sr || !i) {
+      ierr = MatMult(Amat, P, W); CHKERRQ(ierr);                                                                 /* :206 */
+      ierr = VecTDot(P, W, &dpi); CHKERRQ(ierr);                                                                 /* :207 */
+    } else {
+      ierr = VecAYPX(W, beta / betaold, S); CHKERRQ(ierr);                                                       /* :209 */
+      dpi = delta - beta * beta * dpiold / (betaold * betaold);                                                  /* :210 */
+    }
+    betaold = beta;
+    KSPCheckDot(ksp, beta);
+    if ((dpi == 0.0) || ((i > 0) && (dpi * dpiold <= 0.0))) { ksp->reason = KSP_DIVERGED_INDEFINITE_MAT; break; } /* :215-219 */
+    a = beta / dpi;                                                                                              /* :220 */
+    ierr = VecAXPY(X, a, P); CHKERRQ(ierr);                                                                      /* :222 */
+    ierr = VecAXPY(R, -a, W); CHKERRQ(ierr);                                                                     /* :223 */
+    if (ksp->normtype == KSP_NORM_PRECONDITIONED) {
+      ierr = PCApply(ksp->pc, R, Z); CHKERRQ(ierr);                                                              /* :225 */
+      if (sr) { ierr = MatMult(Amat, Z, S); CHKERRQ(ierr); }
+      ierr = VecNorm(Z, NORM_2, &dp); CHKERRQ(ierr);                                                             /* :229 */
+    } else if (ksp->normtype == KSP_NORM_UNPRECONDITIONED) {
+      ierr = VecNorm(R, NORM_2, &dp); CHKERRQ(ierr);                                                             /* :231 */
+    } else if (ksp->normtype == KSP_NORM_NATURAL) {
+      ierr = PCApply(ksp->pc, R, Z); CHKERRQ(ierr);
+      if (sr) {
+        PetscScalar tmp[2]; Vec vecs[2] = {S, R};
+        ierr = MatMult(Amat, Z, S); CHKERRQ(ierr);
+        ierr = VecMDot(Z, 2, vecs, tmp); CHKERRQ(ierr);
+        delta = tmp[0]; beta = tmp[1];
+      } else { ierr = VecTDot(Z, R, &beta); CHKERRQ(ierr); }
+      KSPCheckDot(ksp, beta);
+      dp = sqrt(fabs(beta));
+    } else dp = 0.0;
+    ksp->rnorm = dp;
+    KSPLogResidualHistory(ksp, dp);
+    ierr = KSPConvergedDefault(ksp, i + 1, dp, &ksp->reason); CHKERRQ(ierr);                                     /* :252 */
+    if (ksp->reason) break;
+    if (ksp->normtype != KSP_NORM_PRECONDITIONED && ksp->normtype != KSP_NORM_NATURAL) {
+      ierr = PCApply(ksp->pc, R, Z); CHKERRQ(ierr);                                                              /* :256 */
+      if (sr) { ierr = MatMult(Amat, Z, S); CHKERRQ(ierr); }
+    }
+    if (ksp->normtype != KSP_NORM_NATURAL) {
+      if (sr) {
+        PetscScalar tmp[2]; Vec vecs[2] = {S, R};
+        ierr = VecMDot(Z, 2, vecs, tmp); CHKERRQ(ierr);                                                          /* :266 */
+        delta = tmp[0]; beta = tmp[1];
+      } else { ierr = VecTDot(Z, R, &beta); CHKERRQ(ierr); }                                                     /* :269 */
+      KSPCheckDot(ksp, beta);
+    }
+    i++;
+  } while (i < ksp->max_it);
+  if (i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS;                                                          /* :276 */
+  return 0;
+}
+
+/* ---- GMRES ---- */
+#define VEC_OFFSET 2
+#define VEC_TEMP ksp->vecs[0]
+#define VEC_TEMP_MATOP ksp->vecs[1]
+#define VEC_VV(i) ksp->vecs[(size_t)(VEC_OFFSET + (i))]
+#define HH(a, b) (ksp->hh.data() + (size_t)(b) * (size_t)(ksp->max_k + 2) + (size_t)(a))
+#define GRS(a) (ksp->rs.data() + (a))
+
+/* KSPGMRESGetNewVectors gmres.c:424-450: delta_allocate = 10 more direction vectors */
+static PetscErrorCode KSPGMRESGetNewVectors(KSP ksp, PetscInt it)
+{
+  PetscInt nalloc = 10;
+  const PetscInt total = (PetscInt)ksp->vecs.size();
+  (void)it;
+  if (ksp->vv_allocated + nalloc > total) nalloc = total - ksp->vv_allocated;
+  if (nalloc <= 0) return 0;
+  Vec           *w;
+  PetscErrorCode ierr = VecDuplicateVecs(ksp->vec_sol, nalloc, &w); CHKERRQ(ierr);
+  for (PetscInt q = 0; q < nalloc; q++) ksp->vecs[(size_t)(ksp->vv_allocated + q)] = w[q];
+  free(w);
+  ksp->vv_allocated += nalloc;
+  return 0;
+}
+/* KSPGMRESClassicalGramSchmidtOrthogonalization borthog2.c:36-111 */
+static PetscErrorCode KSPGMRESClassicalGramSchmidt(KSP ksp, PetscInt it)
+{
+  PetscErrorCode ierr;
+  PetscScalar   *hh = HH(0, it), *lhh = ksp->orthogwork.data();
+  bool           refine = (ksp->cgstype == KSP_GMRES_CGS_REFINE_ALWAYS);
+  for (PetscInt j = 0; j <= it; j++) hh[j] = 0.0;
+  ierr = VecMDot(VEC_VV(it + 1), it + 1, &VEC_VV(0), lhh); CHKERRQ(ierr);                   /* :66 */
+  for (PetscInt j = 0; j <= it; j++) { KSPCheckDot(ksp, lhh[j]); lhh[j] = -lhh[j]; }        /* :67-70 */
+  ierr = VecMAXPY(VEC_VV(it + 1), it + 1, lhh, &VEC_VV(0)); CHKERRQ(ierr);                  /* :76 */
+  for (PetscInt j = 0; j <= it; j++) hh[j] -= lhh[j];                                      /* :78-81 */
+  if (ksp->cgstype == KSP_GMRES_CGS_REFINE_IFNEEDED) {                                      /* :87-97 */
+    PetscReal hnrm = 0.0, wnrm;
+    for (PetscInt j = 0; j <= it; j++) hnrm += lhh[j] * lhh[j];
+    hnrm = sqrt(hnrm);
+    ierr = VecNorm(VEC_VV(it + 1), NORM_2, &wnrm); CHKERRQ(ierr);
+    if (wnrm < hnrm) refine = true;
+  }
+  if (refine) {                                                                             /* :99-108 */
+    ierr = VecMDot(VEC_VV(it + 1), it + 1, &VEC_VV(0), lhh); CHKERRQ(ierr);
+    for (PetscInt j = 0; j <= it; j++) lhh[j] = -lhh[j];
+    ierr = VecMAXPY(VEC_VV(it + 1), it + 1, lhh, &VEC_VV(0)); CHKERRQ(ierr);
+    for (PetscInt j = 0; j <= it; j++) hh[j] -= lhh[j];
+  }
+  return 0;
+}
+/* KSPGMRESUpdateHessenberg gmres.c:369-418 */
+static void KSPGMRESUpdateHessenberg(KSP ksp, PetscInt it, bool hapend, PetscReal *res)
+{
+  PetscScalar *hh = HH(0, it), *cc = ksp->cc.data(), *ss = ksp->ss.data(), tt;
+  for (PetscInt j = 1; j <= it; j++) {
+    tt = *hh;
+    *hh = *cc * tt + *ss * *(hh + 1);
+    hh++;
+    *hh = *cc++ * *hh - (*ss++ * tt);
+  }
+  if (!hapend) {
+    tt = sqrt(*hh * *hh + *(hh + 1) * *(hh + 1));
+    if (tt == 0.0) { ksp->reason = KSP_DIVERGED_NULL; return; }
+    *cc = *hh / tt;
+    *ss = *(hh + 1) / tt;
+    *GRS(it + 1) = -(*ss * *GRS(it));
+    *GRS(it) = *cc * *GRS(it);
+    *hh = *cc * *hh + *ss * *(hh + 1);
+    *res = fabs(*GRS(it + 1));
+  } else *res = 0.0;
+}
+/* KSPGMRESBuildSoln gmres.c:316-363 (left preconditioning: KSPUnwindPreconditioner is a no-op, itres.c:114-116) */
+static PetscErrorCode KSPGMRESBuildSoln(KSP ksp, PetscInt it)
+{
+  PetscErrorCode ierr;
+  PetscScalar   *nrs = ksp->nrs.data(), tt;
+  if (it < 0) return 0;
+  if (*HH(it, it) != 0.0) nrs[it] = *GRS(it) / *HH(it, it);
+  else { ksp->reason = KSP_DIVERGED_BREAKDOWN; return 0; }
+  for (PetscInt ii = 1; ii <= it; ii++) {
+    const PetscInt k = it - ii;
+    tt = *GRS(k);
+    for (PetscInt j = k + 1; j <= it; j++) tt = tt - *HH(k, j) * nrs[j];
+    if (*HH(k, k) == 0.0) { ksp->reason = KSP_DIVERGED_BREAKDOWN; return 0; }
+    nrs[k] = tt / *HH(k, k);
+  }
+  ierr = VecSet(VEC_TEMP, 0.0); CHKERRQ(ierr);
+  ierr = VecMAXPY(VEC_TEMP, it + 1, nrs, &VEC_VV(0)); CHKERRQ(ierr);
+  ierr = VecAXPY(ksp->vec_sol, 1.0, VEC_TEMP); CHKERRQ(ierr);
+  return 0;
+}
+/* KSPGMRESCycle gmres.c:118-214 */
+static PetscErrorCode KSPGMRESCycle(PetscInt *itcount, KSP ksp)
+{
+  PetscReal      res_norm, res, hapbnd, tt;
+  PetscErrorCode ierr;
+  PetscInt       it = 0;
+  const PetscInt max_k = ksp->max_k;
+  bool           hapend = false;
+  ierr = VecNormalize(VEC_VV(0), &res_norm); CHKERRQ(ierr);                                 /* :127 */
+  res = res_norm;
+  *GRS(0) = res_norm;
+  ksp->rnorm = res;
+  KSPLogResidualHistory(ksp, res);
+  if (!res) { if (itcount) *itcount = 0; ksp->reason = KSP_CONVERGED_ATOL; return 0; }      /* :138-143 */
+  ierr = KSPConvergedDefault(ksp, ksp->its, res, &ksp->reason); CHKERRQ(ierr);
+  while (!ksp->reason && it < max_k && ksp->its < ksp->max_it) {
+    if (it) KSPLogResidualHistory(ksp, res);
+    if (ksp->vv_allocated <= it + VEC_OFFSET + 1) { ierr = KSPGMRESGetNewVectors(ksp, it + 1); CHKERRQ(ierr); } /* :152-154 */
+    /* KSP_PCApplyBAorAB, left PC: MatMult then PCApply (precon.c:722-734) */
+    ierr = MatMult(ksp->amat, VEC_VV(it), VEC_TEMP_MATOP); CHKERRQ(ierr);
+    ierr = PCApply(ksp->pc, VEC_TEMP_MATOP, VEC_VV(1 + it)); CHKERRQ(ierr);
+    ierr = KSPGMRESClassicalGramSchmidt(ksp, it); CHKERRQ(ierr);                            /* :158 */
+    if (ksp->reason) break;
+    ierr = VecNormalize(VEC_VV(it + 1), &tt); CHKERRQ(ierr);                                /* :162 */
+    *HH(it + 1, it) = tt;
+    hapbnd = fabs(tt / *GRS(it));                                                           /* :169-174 */
+    if (hapbnd > ksp->haptol) hapbnd = ksp->haptol;
+    if (tt < hapbnd) hapend = true;
+    KSPGMRESUpdateHessenberg(ksp, it, hapend, &res);                                        /* :175 */
+    it++;
+    ksp->its++;
+    ksp->rnorm = res;
+    if (ksp->reason) break;
+    ierr = KSPConvergedDefault(ksp, ksp->its, res, &ksp->reason); CHKERRQ(ierr);
+    if (hapend && !ksp->reason) { ksp->reason = KSP_DIVERGED_BREAKDOWN; break; }            /* :186-194 */
+  }
+  if (it && (ksp->reason || ksp->its >= ksp->max_it)) KSPLogResidualHistory(ksp, res);      /* :198-201 */
+  if (itcount) *itcount = it;
+  return KSPGMRESBuildSoln(ksp, it - 1);                                                    /* :212 */
+}
+/* KSPSolve_GMRES gmres.c:218-246 with KSPInitialResidual itres.c:39-70 (left PC) */
+static PetscErrorCode KSPSolve_GMRES(KSP ksp)
+{
+  PetscErrorCode ierr;
+  PetscInt       its, itcount = 0;
+  const bool     guess_zero = ksp->guess_zero;
+  ksp->its = 0;
+  ksp->reason = KSP_CONVERGED_ITERATING;
+  while (!ksp->reason) {
+    if (!ksp->guess_zero) {
+      ierr = MatMult(ksp->amat, ksp->vec_sol, VEC_TEMP); CHKERRQ(ierr);
+      ierr = VecCopy(ksp->vec_rhs, VEC_TEMP_MATOP); CHKERRQ(ierr);
+      ierr = VecAXPY(VEC_TEMP_MATOP, -1.0, VEC_TEMP); CHKERRQ(ierr);
+      ierr = PCApply(ksp->pc, VEC_TEMP_MATOP, VEC_VV(0)); CHKERRQ(ierr);
+    } else {
+      ierr = VecCopy(ksp->vec_rhs, VEC_TEMP_MATOP); CHKERRQ(ierr);
+      ierr = PCApply(ksp->pc, ksp->vec_rhs, VEC_VV(0)); CHKERRQ(ierr);
+    }
+    ierr = KSPGMRESCycle(&its, ksp); CHKERRQ(ierr);
+    itcount += its;
+    if (itcount >= ksp->max_it) { if (!ksp->reason) ksp->reason = KSP_DIVERGED_ITS; break; }
+    ksp->guess_zero = false;
+  }
+  ksp->guess_zero = guess_zero;
+  return 0;
+}
+
+/* KSPSolve itfunc.c:499-611 */
+extern "C" PetscErrorCode KSPSolve(KSP ksp, Vec b, Vec x)
+{
+  if (!ksp || !b || !x) SETERRQ(PETSC_ERR_ARG_NULL, "KSPSolve: null argument");
+  if (b == x) SETERRQ(PETSC_ERR_ARG_IDN, "b and x must be different vectors"); /* itfunc.c:513-519 would duplicate; not supported here */
+  PetscErrorCode ierr;
+  ksp->vec_rhs = b; ksp->vec_sol = x;
+  if (!ksp->amat) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "KSPSolve: call KSPSetOperators() first");
+  if (ksp->amat->m != b->n || ksp->amat->n != x->n) SETERRQ(PETSC_ERR_ARG_SIZ, "KSPSolve: matrix and vector local sizes do not conform");
+  ierr = KSPSetUp(ksp); CHKERRQ(ierr);
+  ksp->guess_zero = ksp->guess_zero_user;
+  if (ksp->guess_zero) { ierr = VecSet(x, 0.0); CHKERRQ(ierr); } /* itfunc.c:580 */
+  ksp->hist_len = 0;
+  ksp->reason = KSP_CONVERGED_ITERATING;
+  if (ksp->type == KSPCG) ierr = KSPSolve_CG(ksp); else ierr = KSPSolve_GMRES(ksp);
+  CHKERRQ(ierr);
+  if (!ksp->reason) SETERRQ(PETSC_ERR_LIB, "Internal error, solver returned without setting converged reason"); /* itfunc.c:607 */
+  return 0;
+}
+extern "C" PetscErrorCode KSPGetIterationNumber(KSP k, PetscInt *its) { if (!k || !its) SETERRQ(PETSC_ERR_ARG_NULL, "null argument"); *its = k->its; return 0; }
+extern "C" PetscErrorCode KSPGetConvergedReason(KSP k, KSPConvergedReason *r) { if (!k || !r) SETERRQ(PETSC_ERR_ARG_NULL, "null argument"); *r = k->reason; return 0; }
+extern "C" PetscErrorCode KSPGetResidualNorm(KSP k, PetscReal *r) { if (!k || !r) SETERRQ(PETSC_ERR_ARG_NULL, "null argument"); *r = k->rnorm; return 0; }
+extern "C" PetscErrorCode KSPDestroy(KSP *ksp)
+{
+  if (!ksp || !*ksp) return 0;
+  PetscErrorCode ierr = ksp_free_work(*ksp); CHKERRQ(ierr);
+  ierr = PCDestroy(&(*ksp)->pc); CHKERRQ(ierr);
+  delete *ksp;
+  *ksp = NULL;
+  return 0;
+}

@@ -90,9 +90,12 @@ struct ThreadGroup {
 static std::map<uint64_t, ThreadGroup *> g_groups;
 static std::mutex                        g_groups_mutex;
 
-enum { BACKEND_SELF = 0, BACKEND_RCCL = 1, BACKEND_THREADS = 2 };
+enum { BACKEND_SELF = 0, BACKEND_RCCL = 1, BACKEND_THREADS = 2, BACKEND_CALLBACKS = 3 };
 
 struct phip_comm_s {
+  phip_allgather_fn     cb_allgather;
+  phip_alltoallv_i32_fn cb_alltoallv;
+  void                 *cb_user;
   phip_ctx     ctx;
   int          backend, rank, size;
   ncclComm_t   nccl;
@@ -134,6 +137,7 @@ extern "C" int phip_comm_create(phip_ctx ctx, const char *backend, const void *i
     c->backend = BACKEND_SELF;
   } else if (!strcmp(backend, "rccl")) {
     PHIP_REQUIRE(id128, PHIP_ERR_ARG_NULL, "phip_comm_create: rccl backend needs the unique id");
+    PHIP_NEED_DEVICE(ctx, "phip_comm_create(rccl)");
     int rc = rccl_load();
     if (rc) { delete c; return rc; }
     ncclUniqueId id;
@@ -157,6 +161,18 @@ extern "C" int phip_comm_create(phip_ctx ctx, const char *backend, const void *i
     delete c;
     PHIP_REQUIRE(0, PHIP_ERR_SUP, "phip_comm_create: unknown backend '%s'", backend);
   }
+  *out = c;
+  return 0;
+}
+
+extern "C" int phip_comm_create_callbacks(phip_ctx ctx, int nranks, int rank, phip_allgather_fn allgather, phip_alltoallv_i32_fn alltoallv,
+                                          void *user, phip_comm *out)
+{
+  PHIP_REQUIRE(ctx && out && allgather && alltoallv, PHIP_ERR_ARG_NULL, "phip_comm_create_callbacks: null argument");
+  PHIP_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create_callbacks: rank %d of %d", rank, nranks);
+  phip_comm c = new phip_comm_s();
+  c->ctx = ctx; c->rank = rank; c->size = nranks; c->nccl = NULL; c->tg = NULL; c->tg_key = 0;
+  c->backend = BACKEND_CALLBACKS; c->cb_allgather = allgather; c->cb_alltoallv = alltoallv; c->cb_user = user;
   *out = c;
   return 0;
 }
@@ -190,7 +206,7 @@ extern "C" int phip_comm_barrier(phip_comm c)
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_comm_barrier: null communicator");
   if (c->backend == BACKEND_THREADS) c->tg->barrier();
-  else if (c->backend == BACKEND_RCCL) {
+  else if (c->backend == BACKEND_RCCL || c->backend == BACKEND_CALLBACKS) {
     int32_t one = 1;
     std::vector<int32_t> all((size_t)c->size);
     return phip_comm_allgather_host(c, &one, all.data(), sizeof(int32_t));
@@ -204,6 +220,8 @@ extern "C" int phip_comm_allreduce(phip_comm c, double *d_buf, int32_t n, int op
   PHIP_REQUIRE(n >= 0 && n <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_allreduce: n=%d", n);
   PHIP_REQUIRE(op == 0 || op == 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_allreduce: op %d", op);
   if (c->size == 1 || n == 0) return 0;
+  PHIP_NEED_DEVICE(c->ctx, "phip_comm_allreduce");
+  PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS, PHIP_ERR_SUP, "phip_comm_allreduce: the callbacks backend carries set-up traffic only");
   if (c->backend == BACKEND_RCCL) {
     PHIP_CHECK_NCCL(g_rccl.AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->nccl, c->ctx->stream));
     return 0;
@@ -231,6 +249,11 @@ extern "C" int phip_comm_allgather_host(phip_comm c, const void *h_send, void *h
 {
   PHIP_REQUIRE(c && h_send && h_recv, PHIP_ERR_ARG_NULL, "phip_comm_allgather_host: null argument");
   if (c->backend == BACKEND_SELF) { memcpy(h_recv, h_send, bytes); return 0; }
+  if (c->backend == BACKEND_CALLBACKS) {
+    int rc = c->cb_allgather(c->cb_user, h_send, h_recv, bytes);
+    PHIP_REQUIRE(rc == 0, PHIP_ERR_LIB, "phip_comm_allgather_host: the application's all-gather callback failed with %d", rc);
+    return 0;
+  }
   if (c->backend == BACKEND_THREADS) {
     ThreadGroup *g = c->tg;
     g->slot_a[(size_t)c->rank] = h_send;
@@ -260,6 +283,11 @@ extern "C" int phip_comm_alltoallv_i32(phip_comm c, const int32_t *h_send, const
   if (c->backend == BACKEND_SELF) {
     PHIP_REQUIRE(send_counts[0] == recv_counts[0], PHIP_ERR_ARG_SIZ, "phip_comm_alltoallv_i32: self counts differ");
     if (send_counts[0]) memcpy(h_recv, h_send, sizeof(int32_t) * (size_t)send_counts[0]);
+    return 0;
+  }
+  if (c->backend == BACKEND_CALLBACKS) {
+    int rc = c->cb_alltoallv(c->cb_user, h_send, send_counts, h_recv, recv_counts);
+    PHIP_REQUIRE(rc == 0, PHIP_ERR_LIB, "phip_comm_alltoallv_i32: the application's all-to-all callback failed with %d", rc);
     return 0;
   }
   if (c->backend == BACKEND_THREADS) {
@@ -320,8 +348,9 @@ extern "C" int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_
   for (int i = 0; i < from_n; i++) PHIP_REQUIRE(from_procs[i] >= 0 && from_procs[i] < comm->size && from_procs[i] != comm->rank && from_starts[i + 1] >= from_starts[i], PHIP_ERR_ARG_OUTOFRANGE, "phip_halo_create: bad receive entry %d", i);
   for (int i = 0; i < h->nsend; i++) PHIP_REQUIRE(to_indices[i] >= 0, PHIP_ERR_ARG_OUTOFRANGE, "phip_halo_create: negative send index");
   phip_ctx ctx = comm->ctx;
-  PHIP_CHECK_HIP(hipSetDevice(ctx->device));
   h->d_to_indices = NULL; h->d_sendbuf = NULL; h->lvec = NULL;
+  if (ctx->device < 0) { *out = h; return 0; } /* planning-only: the plan stays on the host */
+  PHIP_CHECK_HIP(hipSetDevice(ctx->device));
   PHIP_CHECK_HIP(hipMalloc((void **)&h->d_to_indices, sizeof(int32_t) * ((size_t)h->nsend + 4)));
   PHIP_CHECK_HIP(hipMalloc((void **)&h->d_sendbuf, sizeof(double) * ((size_t)h->nsend + 2)));
   if (h->nsend) PHIP_CHECK_HIP(hipMemcpyAsync(h->d_to_indices, to_indices, sizeof(int32_t) * (size_t)h->nsend, hipMemcpyHostToDevice, ctx->stream));
@@ -335,6 +364,7 @@ extern "C" int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_
 extern "C" int phip_halo_destroy(phip_halo h)
 {
   if (!h) return 0;
+  if (h->comm->ctx->device < 0) { delete h; return 0; }
   hipSetDevice(h->comm->ctx->device);
   hipStreamSynchronize(h->comm->ctx->stream);
   hipStreamSynchronize(h->comm->ctx->comm_stream);
@@ -351,6 +381,8 @@ extern "C" int phip_halo_begin(phip_halo h, const double *d_x_local, double *d_l
   phip_ctx  ctx = c->ctx;
   h->lvec = d_lvec;
   if (c->size == 1) return 0;
+  PHIP_NEED_DEVICE(ctx, "phip_halo_begin");
+  PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS, PHIP_ERR_SUP, "phip_halo_begin: the callbacks backend carries set-up traffic only");
   if (h->nsend) {
     hipLaunchKernelGGL(halo_pack_kernel, dim3(phip_grid_for(h->nsend, 1, 1024)), dim3(PHIP_THREADS), 0, ctx->stream, h->nsend, h->d_to_indices, d_x_local, h->d_sendbuf);
     PHIP_CHECK_HIP(hipGetLastError());

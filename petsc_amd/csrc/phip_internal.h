@@ -37,6 +37,10 @@ void phip_set_error(const char *fmt, ...);
     if (!(cond)) { phip_set_error(__VA_ARGS__); return (code); }                                   \
   } while (0)
 
+/* device < 0: planning-only context (no GPU): index/plan work runs, every numerical entry point fails loudly */
+#define PHIP_NEED_DEVICE(c, name) PHIP_REQUIRE((c)->device >= 0, PHIP_ERR_SUP, name ": planning-only context (no GPU): numerical operations are unavailable, there is no CPU fallback")
+#define PHIP_PLANNING_PTR ((void *)(uintptr_t)0x40)
+
 static inline int phip_grid_for(int64_t n, int per_thread, int maxblocks)
 {
   int64_t b = (n + (int64_t)PHIP_THREADS * per_thread - 1) / ((int64_t)PHIP_THREADS * per_thread);

@@ -18,6 +18,13 @@ extern "C" const char *phip_last_error(void) { return g_err; }
 extern "C" int phip_init(int device, phip_ctx *out)
 {
   PHIP_REQUIRE(out, PHIP_ERR_ARG_NULL, "phip_init: null output");
+  if (device == -1) { /* planning-only context: see include/petschip.h */
+    phip_ctx p = (phip_ctx)calloc(1, sizeof(*p));
+    PHIP_REQUIRE(p, PHIP_ERR_MEM, "phip_init: out of host memory");
+    p->device = -1;
+    *out = p;
+    return 0;
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -48,6 +55,7 @@ extern "C" int phip_init(int device, phip_ctx *out)
 extern "C" int phip_finalize(phip_ctx c)
 {
   if (!c) return 0;
+  if (c->device < 0) { free(c); return 0; }
   PHIP_CHECK_HIP(hipSetDevice(c->device));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->comm_stream));
@@ -60,6 +68,13 @@ extern "C" int phip_finalize(phip_ctx c)
 extern "C" int phip_device_info(phip_ctx c, int *device, int *cu_count, size_t *hbm_bytes, char *name, int name_len)
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_device_info: null context");
+  if (c->device < 0) {
+    if (device) *device = -1;
+    if (cu_count) *cu_count = 0;
+    if (hbm_bytes) *hbm_bytes = 0;
+    if (name && name_len > 0) { strncpy(name, "planning-only", (size_t)name_len - 1); name[name_len - 1] = 0; }
+    return 0;
+  }
   hipDeviceProp_t prop;
   PHIP_CHECK_HIP(hipGetDeviceProperties(&prop, c->device));
   if (device) *device = c->device;
@@ -73,6 +88,7 @@ extern "C" int phip_malloc(phip_ctx c, size_t bytes, void **d_ptr)
 {
   PHIP_REQUIRE(c && d_ptr, PHIP_ERR_ARG_NULL, "phip_malloc: null argument");
   *d_ptr = NULL;
+  if (c->device < 0) { *d_ptr = PHIP_PLANNING_PTR; return 0; }
   if (!bytes) bytes = 16; /* zero-length local vectors are legal (veccusp.cu:1017-1020) */
   hipError_t e = hipMalloc(d_ptr, bytes);
   if (e != hipSuccess) { phip_set_error("phip_malloc(%zu): %s", bytes, hipGetErrorString(e)); return PHIP_ERR_MEM; }
@@ -81,7 +97,7 @@ extern "C" int phip_malloc(phip_ctx c, size_t bytes, void **d_ptr)
 
 extern "C" int phip_free(phip_ctx c, void *d_ptr)
 {
-  (void)c;
+  if (c && c->device < 0) return 0;
   if (d_ptr) PHIP_CHECK_HIP(hipFree(d_ptr));
   return 0;
 }
@@ -89,7 +105,7 @@ extern "C" int phip_free(phip_ctx c, void *d_ptr)
 extern "C" int phip_memcpy_h2d(phip_ctx c, void *d_dst, const void *h_src, size_t bytes)
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_memcpy_h2d: null context");
-  if (!bytes) return 0;
+  if (!bytes || c->device < 0) return 0;
   PHIP_CHECK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream)); /* pageable host source may be reused by the caller at once */
   return 0;
@@ -98,6 +114,7 @@ extern "C" int phip_memcpy_h2d(phip_ctx c, void *d_dst, const void *h_src, size_
 extern "C" int phip_memcpy_d2h(phip_ctx c, void *h_dst, const void *d_src, size_t bytes)
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_memcpy_d2h: null context");
+  PHIP_NEED_DEVICE(c, "phip_memcpy_d2h");
   if (bytes) PHIP_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   return 0;
@@ -106,6 +123,7 @@ extern "C" int phip_memcpy_d2h(phip_ctx c, void *h_dst, const void *d_src, size_
 extern "C" int phip_memcpy_d2d(phip_ctx c, void *d_dst, const void *d_src, size_t bytes)
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_memcpy_d2d: null context");
+  PHIP_NEED_DEVICE(c, "phip_memcpy_d2d");
   if (bytes && d_dst != d_src) PHIP_CHECK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
@@ -113,6 +131,7 @@ extern "C" int phip_memcpy_d2d(phip_ctx c, void *d_dst, const void *d_src, size_
 extern "C" int phip_sync(phip_ctx c)
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_sync: null context");
+  if (c->device < 0) return 0;
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -123,6 +142,7 @@ extern "C" int phip_read_scalars(phip_ctx c, const double *d_src, int32_t n, dou
 {
   PHIP_REQUIRE(c && h_dst, PHIP_ERR_ARG_NULL, "phip_read_scalars: null argument");
   PHIP_REQUIRE(n >= 0 && n <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_read_scalars: n=%d", n);
+  PHIP_NEED_DEVICE(c, "phip_read_scalars");
   if (n) PHIP_CHECK_HIP(hipMemcpyAsync(c->h_result, d_src, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   for (int i = 0; i < n; i++) h_dst[i] = c->h_result[i];
@@ -132,6 +152,7 @@ extern "C" int phip_read_scalars(phip_ctx c, const double *d_src, int32_t n, dou
 extern "C" int phip_event_create(phip_ctx c, void **event)
 {
   PHIP_REQUIRE(c && event, PHIP_ERR_ARG_NULL, "phip_event_create: null argument");
+  PHIP_NEED_DEVICE(c, "phip_event_create");
   hipEvent_t e;
   PHIP_CHECK_HIP(hipEventCreate(&e));
   *event = (void *)e;

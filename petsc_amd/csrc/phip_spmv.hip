@@ -200,6 +200,7 @@ static int upload_plan(phip_mat A)
 {
   build_plan(*A->h_rowptr, A->R, A->tpr_user, *A->h_blkrow, *A->h_blktpr);
   A->nblocks = (int32_t)A->h_blktpr->size();
+  if (A->ctx->device < 0) return 0; /* planning-only: the plan stays on the host */
   if (A->d_blkrow) { hipFree(A->d_blkrow); A->d_blkrow = NULL; }
   if (A->d_blktpr) { hipFree(A->d_blktpr); A->d_blktpr = NULL; }
   PHIP_CHECK_HIP(hipMalloc((void **)&A->d_blkrow, sizeof(int32_t) * ((size_t)A->nblocks + 1)));
@@ -222,7 +223,7 @@ extern "C" int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t
   /* operand checks the kernel relies on: monotone row pointer, column range */
   for (int32_t r = 0; r < m; r++) PHIP_REQUIRE(h_i[r + 1] >= h_i[r], PHIP_ERR_ARG_WRONGSTATE, "phip_mat_create: row pointer decreases at row %d", r);
   for (int64_t k = 0; k < nnz; k++) PHIP_REQUIRE(h_j[k] >= 0 && h_j[k] < n, PHIP_ERR_ARG_OUTOFRANGE, "phip_mat_create: column %d out of range [0,%d) at entry %lld", h_j[k], n, (long long)k);
-  PHIP_CHECK_HIP(hipSetDevice(ctx->device));
+  if (ctx->device >= 0) PHIP_CHECK_HIP(hipSetDevice(ctx->device));
   phip_mat A = new phip_mat_s();
   memset(A, 0, sizeof(*A));
   A->ctx = ctx; A->m = m; A->n = n; A->nnz = nnz; A->use_cprow = use_cprow ? 1 : 0;
@@ -237,6 +238,12 @@ extern "C" int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t
     for (int32_t r = 0; r < A->R; r++) PHIP_REQUIRE(h_cprow_rindex[r] >= 0 && h_cprow_rindex[r] < m, PHIP_ERR_ARG_OUTOFRANGE, "phip_mat_create: rindex[%d]=%d", r, h_cprow_rindex[r]);
   }
   const size_t pad = 8;
+  if (ctx->device < 0) { /* planning-only: no device copy */
+    int prc = upload_plan(A);
+    if (prc) return prc;
+    *out = A;
+    return 0;
+  }
   PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rowptr, sizeof(int32_t) * ((size_t)A->R + 1)));
   PHIP_CHECK_HIP(hipMalloc((void **)&A->d_col, sizeof(int32_t) * ((size_t)nnz + pad)));
   PHIP_CHECK_HIP(hipMalloc((void **)&A->d_val, sizeof(double) * ((size_t)nnz + pad)));
@@ -261,6 +268,7 @@ extern "C" int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t
 extern "C" int phip_mat_update_values(phip_mat A, const double *h_a)
 {
   PHIP_REQUIRE(A && (h_a || !A->nnz), PHIP_ERR_ARG_NULL, "phip_mat_update_values: null argument");
+  if (A->ctx->device < 0) return 0;
   PHIP_CHECK_HIP(hipSetDevice(A->ctx->device));
   if (A->nnz) PHIP_CHECK_HIP(hipMemcpyAsync(A->d_val, h_a, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice, A->ctx->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
@@ -270,6 +278,7 @@ extern "C" int phip_mat_update_values(phip_mat A, const double *h_a)
 extern "C" int phip_mat_destroy(phip_mat A)
 {
   if (!A) return 0;
+  if (A->ctx->device < 0) { delete A->h_rowptr; delete A->h_blkrow; delete A->h_blktpr; delete A; return 0; }
   hipSetDevice(A->ctx->device);
   hipStreamSynchronize(A->ctx->stream);
   hipFree(A->d_rowptr); hipFree(A->d_ridx); hipFree(A->d_col); hipFree(A->d_val); hipFree(A->d_blkrow); hipFree(A->d_blktpr);
@@ -290,6 +299,7 @@ static int launch_spmv(phip_mat A, const double *d_x, const double *d_yin, doubl
 extern "C" int phip_mat_mult(phip_mat A, const double *d_x, double *d_y)
 {
   PHIP_REQUIRE(A && (d_y || !A->m) && (d_x || !A->nnz), PHIP_ERR_ARG_NULL, "phip_mat_mult: null argument");
+  PHIP_NEED_DEVICE(A->ctx, "phip_mat_mult");
   PHIP_REQUIRE(d_x != d_y || !A->m, PHIP_ERR_ARG_SIZ, "phip_mat_mult: x and y must be different vectors (matrix.c:2213)");
   if (A->use_cprow && A->m) PHIP_CHECK_HIP(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)A->m, A->ctx->stream)); /* aij.c:1296 */
   return launch_spmv(A, d_x, NULL, d_y, 0);
@@ -298,6 +308,7 @@ extern "C" int phip_mat_mult(phip_mat A, const double *d_x, double *d_y)
 extern "C" int phip_mat_multadd(phip_mat A, const double *d_x, const double *d_y, double *d_z)
 {
   PHIP_REQUIRE(A && ((d_y && d_z) || !A->m) && (d_x || !A->nnz), PHIP_ERR_ARG_NULL, "phip_mat_multadd: null argument");
+  PHIP_NEED_DEVICE(A->ctx, "phip_mat_multadd");
   PHIP_REQUIRE(d_x != d_z || !A->m, PHIP_ERR_ARG_SIZ, "phip_mat_multadd: x and z must be different vectors (matrix.c:2361)");
   if (A->use_cprow && d_z != d_y && A->m)
     PHIP_CHECK_HIP(hipMemcpyAsync(d_z, d_y, sizeof(double) * (size_t)A->m, hipMemcpyDeviceToDevice, A->ctx->stream)); /* aij.c:1460-1462 */
@@ -307,6 +318,7 @@ extern "C" int phip_mat_multadd(phip_mat A, const double *d_x, const double *d_y
 extern "C" int phip_mat_getdiagonal(phip_mat A, double *d_v)
 {
   PHIP_REQUIRE(A && (d_v || !A->m), PHIP_ERR_ARG_NULL, "phip_mat_getdiagonal: null argument");
+  PHIP_NEED_DEVICE(A->ctx, "phip_mat_getdiagonal");
   if (!A->m) return 0;
   PHIP_CHECK_HIP(hipMemsetAsync(d_v, 0, sizeof(double) * (size_t)A->m, A->ctx->stream)); /* VecSet(v,0) aij.c:1188 */
   if (A->R) {

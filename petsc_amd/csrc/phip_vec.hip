@@ -244,7 +244,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void jacobi_setup_kernel(int32_t n, d
 
 /* ---- host launchers ---------------------------------------------------------------------------- */
 #define EW_GRID(n) phip_grid_for((n) / 2 + 1, 4, 2048)
-#define CHECK_CTX(c, name) PHIP_REQUIRE((c), PHIP_ERR_ARG_NULL, name ": null context")
+#define CHECK_CTX(c, name) do { PHIP_REQUIRE((c), PHIP_ERR_ARG_NULL, name ": null context"); PHIP_NEED_DEVICE((c), name); } while (0)
 #define CHECK_N(n, name) PHIP_REQUIRE((n) >= 0, PHIP_ERR_ARG_OUTOFRANGE, name ": negative length %d", (n))
 
 template <int OP, bool HX, bool HY, bool HZ>
@@ -462,6 +462,7 @@ extern "C" int phip_vec_norm(phip_ctx c, int32_t n, const double *d_x, int type,
     return 0;
   }
   PHIP_REQUIRE(0, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_norm: unknown NormType %d", type);
+  return PHIP_ERR_ARG_OUTOFRANGE;
 }
 
 template <int NV>
