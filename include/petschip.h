@@ -68,6 +68,7 @@ int         phip_memcpy_h2d(phip_ctx ctx, void *d_dst, const void *h_src, size_t
 int         phip_memcpy_d2h(phip_ctx ctx, void *h_dst, const void *d_src, size_t bytes); /* VecCUSPCopyFromGPU veccusp.cu:152 (synchronises) */
 int         phip_memcpy_d2d(phip_ctx ctx, void *d_dst, const void *d_src, size_t bytes);
 int         phip_sync(phip_ctx ctx);                                                     /* WaitForGPU, cuspvecimpl.h:66 */
+int         phip_device_sync(phip_ctx ctx);                                              /* hipDeviceSynchronize: every stream of the device */
 void       *phip_stream(phip_ctx ctx);          /* the hipStream_t all work is issued on */
 /* hipEvent timing on the context's stream (PetscLogEventBegin/End's role for device work, include/petsclog.h:284-295):
  * record two events around a region, then phip_event_elapsed_ms synchronises on the second and returns the device time. */
@@ -75,6 +76,12 @@ int         phip_event_create(phip_ctx ctx, void **event);
 int         phip_event_record(phip_ctx ctx, void *event);
 int         phip_event_elapsed_ms(phip_ctx ctx, void *start, void *stop, float *ms);
 int         phip_event_destroy(phip_ctx ctx, void *event);
+/* Per-launch device timing of the SpMV kernel (the role of the MAT_Mult event of -log_view, src/mat/interface/matrix.c:2224-2226):
+ * while enabled, every phip_mat_mult (kind 0) / phip_mat_multadd (kind 1) launch is bracketed by a hipEvent pair on the compute
+ * stream.  phip_profile_read synchronises and returns the number of launches recorded since enable and their summed / extreme
+ * durations in ms.  Enabling (or re-enabling) clears the records. */
+int         phip_profile_enable(phip_ctx ctx, int on);
+int         phip_profile_read(phip_ctx ctx, int kind, int32_t *count, double *sum_ms, double *min_ms, double *max_ms);
 
 /* ---- device CSR matrix (Mat_SeqAIJ on the GPU) --------------------------------------------------
  * phip_mat_create uploads a host CSR exactly as MatAssemblyEnd_SeqAIJ leaves it (src/mat/impls/aij/seq/aij.c:

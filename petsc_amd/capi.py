@@ -23,11 +23,14 @@ SIGNATURES = [
     ("phip_memcpy_d2h", C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     ("phip_memcpy_d2d", C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     ("phip_sync", C.c_int, [_vp]),
+    ("phip_device_sync", C.c_int, [_vp]),
     ("phip_stream", _vp, [_vp]),
     ("phip_event_create", C.c_int, [_vp, C.POINTER(_vp)]),
     ("phip_event_record", C.c_int, [_vp, _vp]),
     ("phip_event_elapsed_ms", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float)]),
     ("phip_event_destroy", C.c_int, [_vp, _vp]),
+    ("phip_profile_enable", C.c_int, [_vp, C.c_int]),
+    ("phip_profile_read", C.c_int, [_vp, C.c_int, _pI, _pD, _pD, _pD]),
     ("phip_mat_create", C.c_int, [_vp, C.c_int32, C.c_int32, _pI, _pI, _pD, C.c_int, C.c_int32, _pI, _pI, C.POINTER(_vp)]),
     ("phip_mat_update_values", C.c_int, [_vp, _pD]),
     ("phip_mat_destroy", C.c_int, [_vp]),

@@ -19,7 +19,12 @@ struct phip_ctx_s {
   double      *h_result;    // pinned host mirror of d_result
   int         *d_flag;      // small int scratch (jacobi zero flag)
   int         *h_flag;      // pinned
+  int          prof_on;     // phip_profile_enable: hipEvent pair around every SpMV launch
+  struct phip_prof_s *prof;
 };
+
+/* profiling records (phip_runtime.hip): kind 0 = MatMult launches, 1 = MatMultAdd launches */
+int phip_prof_open(phip_ctx c, int kind, hipEvent_t *start, hipEvent_t *stop);
 
 void phip_set_error(const char *fmt, ...);
 

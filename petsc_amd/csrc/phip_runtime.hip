@@ -2,6 +2,12 @@
 #include "phip_internal.h"
 #include <stdarg.h>
 #include <stdlib.h>
+#include <vector>
+
+struct phip_prof_s {
+  std::vector<hipEvent_t> ev[2][2]; /* [kind][start|stop] */
+  size_t                  used[2];
+};
 
 static thread_local char g_err[512] = "";
 
@@ -60,6 +66,10 @@ extern "C" int phip_finalize(phip_ctx c)
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->comm_stream));
   hipFree(c->d_partials); hipFree(c->d_result); hipHostFree(c->h_result); hipFree(c->d_flag); hipHostFree(c->h_flag);
+  if (c->prof) {
+    for (int k = 0; k < 2; k++) for (int w = 0; w < 2; w++) for (hipEvent_t e : c->prof->ev[k][w]) hipEventDestroy(e);
+    delete c->prof;
+  }
   hipStreamDestroy(c->stream); hipStreamDestroy(c->comm_stream);
   free(c);
   return 0;
@@ -136,6 +146,15 @@ extern "C" int phip_sync(phip_ctx c)
   return 0;
 }
 
+extern "C" int phip_device_sync(phip_ctx c)
+{
+  PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_device_sync: null context");
+  if (c->device < 0) return 0;
+  PHIP_CHECK_HIP(hipSetDevice(c->device));
+  PHIP_CHECK_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
 extern "C" void *phip_stream(phip_ctx c) { return c ? (void *)c->stream : NULL; }
 
 extern "C" int phip_read_scalars(phip_ctx c, const double *d_src, int32_t n, double *h_dst)
@@ -178,5 +197,57 @@ extern "C" int phip_event_destroy(phip_ctx c, void *event)
 {
   (void)c;
   if (event) PHIP_CHECK_HIP(hipEventDestroy((hipEvent_t)event));
+  return 0;
+}
+
+/* ---- per-launch device timing of the SpMV kernel (bench.py's roofline leg) ------------------------- */
+
+int phip_prof_open(phip_ctx c, int kind, hipEvent_t *start, hipEvent_t *stop)
+{
+  if (!c->prof) { c->prof = new phip_prof_s(); c->prof->used[0] = c->prof->used[1] = 0; }
+  phip_prof_s *p = c->prof;
+  if (p->used[kind] == p->ev[kind][0].size()) {
+    hipEvent_t a, b;
+    PHIP_CHECK_HIP(hipEventCreate(&a));
+    PHIP_CHECK_HIP(hipEventCreate(&b));
+    p->ev[kind][0].push_back(a); p->ev[kind][1].push_back(b);
+  }
+  *start = p->ev[kind][0][p->used[kind]];
+  *stop = p->ev[kind][1][p->used[kind]];
+  p->used[kind]++;
+  return 0;
+}
+
+extern "C" int phip_profile_enable(phip_ctx c, int on)
+{
+  PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_profile_enable: null context");
+  PHIP_NEED_DEVICE(c, "phip_profile_enable");
+  c->prof_on = on ? 1 : 0;
+  if (c->prof) c->prof->used[0] = c->prof->used[1] = 0;
+  return 0;
+}
+
+extern "C" int phip_profile_read(phip_ctx c, int kind, int32_t *count, double *sum_ms, double *min_ms, double *max_ms)
+{
+  PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_profile_read: null context");
+  PHIP_REQUIRE(kind == 0 || kind == 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_profile_read: kind %d", kind);
+  PHIP_NEED_DEVICE(c, "phip_profile_read");
+  PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
+  double  s = 0.0, lo = 0.0, hi = 0.0;
+  int32_t n = 0;
+  if (c->prof) {
+    for (size_t k = 0; k < c->prof->used[kind]; k++) {
+      float ms = 0.f;
+      PHIP_CHECK_HIP(hipEventElapsedTime(&ms, c->prof->ev[kind][0][k], c->prof->ev[kind][1][k]));
+      s += ms;
+      if (!n || ms < lo) lo = ms;
+      if (!n || ms > hi) hi = ms;
+      n++;
+    }
+  }
+  if (count) *count = n;
+  if (sum_ms) *sum_ms = s;
+  if (min_ms) *min_ms = lo;
+  if (max_ms) *max_ms = hi;
   return 0;
 }

@@ -290,9 +290,16 @@ extern "C" int phip_mat_destroy(phip_mat A)
 static int launch_spmv(phip_mat A, const double *d_x, const double *d_yin, double *d_yout, int add)
 {
   if (!A->nblocks) return 0;
+  hipEvent_t e0 = NULL, e1 = NULL;
+  if (A->ctx->prof_on) {
+    int rc = phip_prof_open(A->ctx, add ? 1 : 0, &e0, &e1);
+    if (rc) return rc;
+    PHIP_CHECK_HIP(hipEventRecord(e0, A->ctx->stream));
+  }
   hipLaunchKernelGGL(spmv_rowblock_kernel, dim3((unsigned)A->nblocks), dim3(PHIP_THREADS), 0, A->ctx->stream, A->d_blkrow, A->d_blktpr, A->d_rowptr,
                      A->d_ridx, A->d_col, A->d_val, d_x, d_yin, d_yout, add, A->use_cprow);
   PHIP_CHECK_HIP(hipGetLastError());
+  if (e1) PHIP_CHECK_HIP(hipEventRecord(e1, A->ctx->stream));
   return 0;
 }
 

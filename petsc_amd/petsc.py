@@ -7,6 +7,7 @@ There is no CPU fallback: a missing library raises ImportError.
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 
@@ -132,6 +133,52 @@ class Comm:
         chk(lib().PetscCommGetContext(self.h, C.byref(ctx)))
         self.ctx = ctx
 
+    @classmethod
+    def from_callbacks(cls, device, nranks, rank, allgather, alltoallv):
+        """PetscHipInitializeWithCallbacks: set-up collectives supplied by the application (see petsc_amd/torchcomm.py).
+        allgather(send: bytes) -> bytes of all ranks in rank order; alltoallv(send: int32 array, send_counts) -> (recv, ...)."""
+        self = cls.__new__(cls)
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+        AV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32))
+
+        def _ag(user, send, recv, nbytes):
+            try:
+                data = C.string_at(send, nbytes) if nbytes else b""
+                out = allgather(data)
+                assert len(out) == nbytes * nranks
+                C.memmove(recv, out, len(out))
+                return 0
+            except Exception as e:  # the C side turns this into PHIP_ERR_LIB
+                sys.stderr.write("allgather callback failed: %r\n" % (e,))
+                return 1
+
+        def _av(user, send, scounts, recv, rcounts):
+            try:
+                sc = np.array([scounts[i] for i in range(nranks)], np.int32)
+                rc = np.array([rcounts[i] for i in range(nranks)], np.int32)
+                tot = int(sc.sum())
+                sbuf = np.ctypeslib.as_array(send, shape=(max(tot, 1),))[:tot].copy() if tot else np.zeros(0, np.int32)
+                out = np.ascontiguousarray(alltoallv(sbuf, sc, rc), np.int32)
+                assert len(out) == int(rc.sum())
+                if len(out):
+                    C.memmove(recv, out.ctypes.data, 4 * len(out))
+                return 0
+            except Exception as e:
+                sys.stderr.write("alltoallv callback failed: %r\n" % (e,))
+                return 1
+
+        self._cb = (AG(_ag), AV(_av))  # keep the thunks alive as long as the communicator
+        self.h = C.c_void_p()
+        chk(lib().PetscHipInitializeWithCallbacks(device, nranks, rank, C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None, C.byref(self.h)))
+        self.rank, self.size = rank, nranks
+        s = C.c_void_p()
+        chk(lib().PetscCommGetSelf(self.h, C.byref(s)))
+        self.self_h = s
+        ctx = C.c_void_p()
+        chk(lib().PetscCommGetContext(self.h, C.byref(ctx)))
+        self.ctx = ctx
+        return self
+
     @property
     def SELF(self):
         c = Comm.__new__(Comm)
@@ -202,8 +249,8 @@ class Vec:
 
     def array(self):
         p = C.c_void_p()
-        chk(lib().VecGetArrayRead(self.h, C.byref(p)))
         n = self.local_size
+        chk(lib().VecGetArrayRead(self.h, C.byref(p)))
         out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(max(n, 1),))[:n].copy() if n else np.zeros(0)
         chk(lib().VecRestoreArrayRead(self.h, C.byref(p)))
         return out
@@ -211,9 +258,9 @@ class Vec:
     def set_array(self, arr):
         arr = _f64(arr)
         p = C.c_void_p()
-        chk(lib().VecGetArray(self.h, C.byref(p)))
         n = self.local_size
         assert len(arr) == n
+        chk(lib().VecGetArray(self.h, C.byref(p)))
         if n:
             C.memmove(p, arr.ctypes.data, 8 * n)
         chk(lib().VecRestoreArray(self.h, C.byref(p)))

@@ -1,0 +1,454 @@
+"""GPU parity tests of the PETSc-API mirror (libpetschip_host.so -> libpetschip.so) against the oracle and the reference's
+golden outputs.  Bars (BASELINE.json): index work bit-exact; SpMV <= 1e-12 relative; KSP +-1 iteration and <= 1e-10 relative
+final residual (relative to the initial residual norm); 6-digit -ksp_monitor_short histories equal to the reference's files.
+
+Multi-rank cases use the "threads" communicator: the ranks are host threads of this process sharing the one GPU, so the
+whole distributed code path (row split, stash, garray, scatter plan, device pack kernel, lvec offsets, MultAdd on the
+compressed-row off-diagonal block, all-reduce ordering) runs on a single-GPU box.
+"""
+import os
+import struct
+import threading
+
+import numpy as np
+import pytest
+
+from oracle.oracle import REFINE_ALWAYS, REFINE_IFNEEDED, REFINE_NEVER
+
+pytestmark = pytest.mark.gpu
+
+_key = [1000]
+
+
+def run_ranks(n, fn):
+    """Run fn(comm) on n ranks (threads backend; n == 1 -> self). Returns the list of results in rank order."""
+    from petsc_amd import petsc as P
+    if n == 1:
+        comm = P.Comm(device=0, backend="self")
+        try:
+            return [fn(comm)]
+        finally:
+            comm.finalize()
+    _key[0] += 1
+    key = struct.pack("<Q", _key[0]) + bytes(120)
+    res, err = [None] * n, [None] * n
+
+    def work(r):
+        comm = None
+        try:
+            comm = P.Comm(device=0, backend="threads", id128=key, nranks=n, rank=r)
+            res[r] = fn(comm)
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+        finally:
+            if comm is not None and err[r] is None:
+                comm.finalize()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    for r in range(n):
+        if err[r] is not None:
+            raise err[r]
+    return res
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, "mat_%s.npz" % name), allow_pickle=False)
+
+
+def gather(parts):
+    return np.concatenate(parts)
+
+
+def local_slice(comm, N):
+    m = N // comm.size + (1 if (N % comm.size) > comm.rank else 0)
+    rs = sum(N // comm.size + (1 if (N % comm.size) > r else 0) for r in range(comm.rank))
+    return rs, rs + m
+
+
+def monitor_short(v):
+    if v > 1e-9:
+        return "%g" % v
+    if v > 1e-11:
+        return "%5.3e" % v
+    return "< 1.e-11"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_vec_closed_forms_ex1():
+    """src/vec/vec/examples/tutorials/ex1.c:71-153 (golden output ex1_1.out: every error prints 0)."""
+    from petsc_amd import petsc as P
+
+    def body(comm):
+        n = 20
+        x = P.Vec(comm, P.PETSC_DECIDE, n, "hip")
+        y, w = x.duplicate(), x.duplicate()
+        z = [x.duplicate() for _ in range(3)]
+        one, two, three = 1.0, 2.0, 3.0
+        x.set(one); y.set(two); z[0].set(one); z[1].set(two); z[2].set(three)
+        assert x.dot(x) == n
+        np.testing.assert_array_equal(x.mdot(z), [n, 2 * n, 3 * n])
+        x.scale(two)
+        assert abs(x.norm() - 2 * np.sqrt(n)) < 1e-14 * n
+        y.copy_to(w)
+        assert abs(w.norm() - 2 * np.sqrt(n)) < 1e-14 * n
+        y.axpy(three, x)
+        assert abs(y.norm() - 8 * np.sqrt(n)) < 1e-13 * n
+        y.aypx(two, x)
+        assert abs(y.norm() - 18 * np.sqrt(n)) < 1e-13 * n
+        x.swap(y)
+        assert abs(y.norm() - 2 * np.sqrt(n)) < 1e-13 * n and abs(x.norm() - 18 * np.sqrt(n)) < 1e-13 * n
+        w.waxpy(two, x, y)
+        assert abs(w.norm() - 38 * np.sqrt(n)) < 1e-12 * n
+        w.pointwise_mult(y, x)
+        assert abs(w.norm() - 36 * np.sqrt(n)) < 1e-12 * n
+        w.pointwise_divide(x, y)
+        assert abs(w.norm() - 9 * np.sqrt(n)) < 1e-12 * n
+        x.set(one)
+        x.maxpy([one, two, three], z)  # 1 + 1 + 4 + 9
+        assert abs(x.norm() - 15 * np.sqrt(n)) < 1e-12 * n
+        assert x.norm(P.NORM_1) == 15.0 * n and x.norm(P.NORM_INFINITY) == 15.0
+        n1, n2 = x.norm(P.NORM_1_AND_2)
+        assert n1 == 15.0 * n and abs(n2 - 15 * np.sqrt(n)) < 1e-12 * n
+        assert abs(x.normalize() - 15 * np.sqrt(n)) < 1e-12 * n and abs(x.norm() - 1.0) < 1e-14
+        with pytest.raises(P.PetscError) as e:
+            x.axpy(1.0, x)
+        assert e.value.code == 61
+        for v in [x, y, w] + z:
+            v.destroy()
+        return True
+
+    for size in (1, 2, 3):
+        assert all(run_ranks(size, body))
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64"])
+@pytest.mark.parametrize("size", [1, 2, 3, 4])
+def test_matmult_golden(orc, golden_dir, name, size):
+    from petsc_amd import petsc as P
+    g = load(golden_dir, name)
+    N = int(g["N"])
+    if int(g["M"]) != N:
+        pytest.skip("rectangular")
+    if size > 1 and "s%d_ranges" % size not in g.files:
+        pytest.skip("no fixture for this split")
+
+    def body(comm):
+        rs, re = local_slice(comm, N)
+        A = P.Mat.from_global_csr(comm, g["i"], g["j"], g["a"])
+        x = P.Vec.from_array(comm, g["x"][rs:re], N)
+        y = x.duplicate()
+        A.mult(x, y)
+        out = [y.array()]
+        y0 = P.Vec.from_array(comm, g["y0"][rs:re], N)
+        z = x.duplicate()
+        A.mult_add(x, y0, z)
+        out.append(z.array())
+        A.mult_add(x, y0, y0)  # in place, as MatMult_MPIAIJ calls it (mpiaij.c:996)
+        out.append(y0.array())
+        d = x.duplicate()
+        A.get_diagonal(d)
+        out.append(d.array())
+        if comm.size > 1:
+            gh = A.ghosts()
+            pre = "s%d_" % comm.size
+            np.testing.assert_array_equal(gh["garray"], g[pre + "garray_%d" % comm.rank])
+            for key in ("from_procs", "from_starts", "to_procs", "to_starts", "to_indices"):
+                np.testing.assert_array_equal(gh[key], g[pre + "%s_%d" % (key, comm.rank)], err_msg=key)
+        for o in (x, y, y0, z, d, A):
+            o.destroy()
+        return out
+
+    res = run_ranks(size, body)
+    y = gather([r[0] for r in res]); z = gather([r[1] for r in res]); z2 = gather([r[2] for r in res]); d = gather([r[3] for r in res])
+    scale = np.abs(g["y"]).max() + 1e-300
+    assert np.abs(y - g["y"]).max() <= 1e-12 * scale
+    zo = orc.matmultadd(g["i"], g["j"], g["a"], g["x"], g["y0"])
+    assert np.abs(z - zo).max() <= 1e-12 * (scale + 1) and np.abs(z2 - zo).max() <= 1e-12 * (scale + 1)
+    np.testing.assert_array_equal(d, g["diag"])
+
+
+def ksp_case(comm, ai, aj, aa, b_global, ksp_type, pc="jacobi", x0=None, **opts):
+    from petsc_amd import petsc as P
+    N = len(ai) - 1
+    rs, re = local_slice(comm, N)
+    A = P.Mat.from_global_csr(comm, ai, aj, aa)
+    b = P.Vec.from_array(comm, b_global[rs:re], N)
+    x = b.duplicate()
+    ksp = P.KSP(comm, ksp_type, pc)
+    ksp.set_operators(A)
+    ksp.set_tolerances(rtol=opts.get("rtol", P.PETSC_DEFAULT), max_it=opts.get("max_it", P.PETSC_DEFAULT))
+    if "normtype" in opts:
+        ksp.set_norm_type(opts["normtype"])
+    if "restart" in opts:
+        ksp.gmres_set_restart(opts["restart"])
+    if "cgs_refine" in opts:
+        ksp.gmres_set_cgs_refinement(opts["cgs_refine"])
+    if opts.get("single_reduction"):
+        ksp.cg_set_single_reduction(True)
+    if opts.get("useabs"):
+        ksp.pc_jacobi_set_use_abs(True)
+    if x0 is not None:
+        x.set_array(x0[rs:re])
+        ksp.set_initial_guess_nonzero(True)
+    ksp.set_residual_history()
+    res = ksp.solve(b, x)
+    res["x"] = x.array()
+    for o in (ksp, x, b, A):
+        o.destroy()
+    return res
+
+
+def check_ksp(res_ranks, ref):
+    r0 = res_ranks[0]
+    x = gather([r["x"] for r in res_ranks])
+    assert r0["reason"] == ref["reason"], (r0["reason"], ref["reason"])
+    assert abs(r0["its"] - ref["its"]) <= 1, (r0["its"], ref["its"])
+    rn0 = ref["history"][0] if len(ref["history"]) else 1.0
+    if r0["its"] == ref["its"]:
+        assert abs(r0["rnorm"] - ref["rnorm"]) <= 1e-10 * rn0, (r0["rnorm"], ref["rnorm"])
+        k = min(len(r0.get("history", [])), len(ref["history"]))
+        assert k == 0 or np.abs(r0["history"][:k] - ref["history"][:k]).max() <= 1e-9 * rn0
+    assert np.abs(x - ref["x"]).max() <= 1e-6 * (np.abs(ref["x"]).max() + 1e-300)
+
+
+@pytest.mark.parametrize("size", [1, 2, 4])
+def test_cg_jacobi_parity(orc, golden_dir, size):
+    from petsc_amd import generators as G
+    g = load(golden_dir, "spd-real-int32-float64")
+    cases = [((g["i"], g["j"], g["a"]), g["vec0"], dict(rtol=1e-12))]
+    for gen in (G.laplace3d_7pt(14, dirichlet_rows=False), G.box3d_27pt(11), G.laplace2d_5pt(40, 37)):
+        n = len(gen[0]) - 1
+        op = orc.operator(*gen, 1)
+        cases.append((gen, op.mult(np.ones(n)), dict(rtol=1e-8)))
+    for (ai, aj, aa), b, opts in cases:
+        ref = orc.operator(ai, aj, aa, size).solve(b, "cg", "jacobi", **opts)
+        check_ksp(run_ranks(size, lambda comm: ksp_case(comm, ai, aj, aa, b, "cg", **opts)), ref)
+
+
+def test_cg_variants(orc):
+    """norm types (cg.c:136-160), -ksp_cg_single_reduction (cg.c:226-243), non-zero initial guess (cg.c:131-132)."""
+    from petsc_amd import generators as G, petsc as P
+    ai, aj, aa = G.laplace3d_7pt(12, dirichlet_rows=False)
+    n = len(ai) - 1
+    op = orc.operator(ai, aj, aa, 1)
+    b = op.mult(np.linspace(-1, 1, n))
+    for nt in (P.KSP_NORM_PRECONDITIONED, P.KSP_NORM_UNPRECONDITIONED, P.KSP_NORM_NATURAL):
+        ref = op.solve(b, "cg", "jacobi", rtol=1e-9, normtype=nt)
+        check_ksp(run_ranks(1, lambda comm: ksp_case(comm, ai, aj, aa, b, "cg", rtol=1e-9, normtype=nt)), ref)
+    x0 = np.cos(np.arange(n))
+    ref = op.solve(b, "cg", "jacobi", rtol=1e-9, x0=x0)
+    check_ksp(run_ranks(2, lambda comm: ksp_case(comm, ai, aj, aa, b, "cg", rtol=1e-9, x0=x0)), ref)
+    ref = op.solve(b, "cg", "jacobi", rtol=1e-9)
+    res = run_ranks(1, lambda comm: ksp_case(comm, ai, aj, aa, b, "cg", rtol=1e-9, single_reduction=True))
+    assert abs(res[0]["its"] - ref["its"]) <= 1 and res[0]["reason"] == 2
+    assert np.abs(res[0]["x"] - ref["x"]).max() <= 1e-6 * np.abs(ref["x"]).max()
+    ref = op.solve(b, "cg", "none", rtol=1e-9)
+    check_ksp(run_ranks(1, lambda comm: ksp_case(comm, ai, aj, aa, b, "cg", pc="none", rtol=1e-9)), ref)
+
+
+@pytest.mark.parametrize("size", [1, 3])
+def test_gmres_jacobi_parity(orc, golden_dir, size):
+    from petsc_amd import generators as G
+    ai, aj, aa = G.convdiff3d_7pt(13, 11, 9)
+    n = len(ai) - 1
+    b = orc.operator(ai, aj, aa, 1).mult(np.ones(n))
+    for refine in (REFINE_NEVER, REFINE_IFNEEDED, REFINE_ALWAYS):
+        for restart in (30, 7):
+            ref = orc.operator(ai, aj, aa, size).solve(b, "gmres", "jacobi", rtol=1e-9, restart=restart, cgs_refine=refine)
+            check_ksp(run_ranks(size, lambda comm: ksp_case(comm, ai, aj, aa, b, "gmres", rtol=1e-9, restart=restart, cgs_refine=refine)), ref)
+    g = load(golden_dir, "ns-real-int32-float64")
+    ref = orc.operator(g["i"], g["j"], g["a"], size).solve(g["vec0"], "gmres", "jacobi", rtol=1e-10)
+    check_ksp(run_ranks(size, lambda comm: ksp_case(comm, g["i"], g["j"], g["a"], g["vec0"], "gmres", rtol=1e-10)), ref)
+
+
+EX3_1_OUT = ["0.541987", "0.327572", "0.201868", "0.146074", "0.102129", "0.0549947", "0.0216871", "< 1.e-11"]
+EX5_1_OUT = [["4.16083", "1.32287", "0.625076", "0.211511", "0.0201553", "< 1.e-11"],
+             ["5.16667", "1.01143", "0.241047", "0.0452703", "0.00290094", "< 1.e-11"]]
+
+
+@pytest.mark.parametrize("size", [1, 2])
+def test_ex3_golden_history(size):
+    """src/ksp/ksp/examples/tests/ex3.c end to end through the mirrored API: element-by-element ADD_VALUES assembly (rank r
+    inserts elements r, r+size, ... so off-process rows go through the stash), MatZeroRows on the boundary, GMRES + Jacobi
+    with -ksp_gmres_cgs_refinement_type refine_always; the residual history must print as tests/output/ex3_1.out."""
+    from petsc_amd import petsc as P
+    m = 5
+    N = (m + 1) ** 2
+    h = 1.0 / m
+    H = h * h
+    Ke = np.array([H / 6, -.125 * H, H / 12, -.125 * H, -.125 * H, H / 6, -.125 * H, H / 12,
+                   H / 12, -.125 * H, H / 6, -.125 * H, -.125 * H, H / 12, -.125 * H, H / 6])
+
+    def body(comm):
+        A = P.Mat(comm, P.PETSC_DECIDE, P.PETSC_DECIDE, N, N, "aijhip")
+        A.set_up()
+        for e in range(comm.rank, m * m, comm.size):
+            i0 = (m + 1) * (e // m) + (e % m)
+            idx = [i0, i0 + 1, i0 + m + 2, i0 + m + 1]
+            A.set_values(idx, idx, Ke, P.ADD_VALUES)
+        A.assemble()
+        rs, re = A.ownership_range()
+        u, b = A.create_vecs()
+        brows = [r for r in range(rs, re) if r // (m + 1) in (0, m) or r % (m + 1) in (0, m)]
+        vals = [h * (r // (m + 1)) for r in brows]
+        u.set_values(brows, vals); u.assemble()
+        b.set_values(brows, vals); b.assemble()
+        A.zero_rows(brows, 1.0)
+        ksp = P.KSP(comm, "gmres", "jacobi")
+        ksp.set_operators(A)
+        ksp.set_initial_guess_nonzero(True)
+        ksp.gmres_set_cgs_refinement(P.REFINE_ALWAYS)
+        ksp.set_residual_history()
+        res = ksp.solve(b, u)
+        res["x"] = u.array()
+        for o in (ksp, u, b, A):
+            o.destroy()
+        return res
+
+    res = run_ranks(size, body)
+    assert [monitor_short(v) for v in res[0]["history"]] == EX3_1_OUT
+    assert res[0]["its"] == 7 and res[0]["reason"] == 2
+    ustar = np.array([h * (i // (m + 1)) for i in range(N)])
+    assert np.linalg.norm(gather([r["x"] for r in res]) - ustar) < 1e-13
+
+
+def test_ex5_golden_history():
+    """src/ksp/ksp/examples/tutorials/ex5.c (two solves, the second after re-assembling new values into the same pattern)."""
+    from petsc_amd import petsc as P
+    m, n = 3, 2
+
+    def body(comm):
+        A = P.Mat(comm, m * n, m * n, m * n, m * n, "aijhip")
+        A.seqaij_set_preallocation(5)
+        ksp = P.KSP(comm, "gmres", "jacobi")
+        ksp.gmres_set_cgs_refinement(P.REFINE_ALWAYS)
+        ksp.set_residual_history()
+        hists = []
+        for dv in (4.0, 6.0):
+            if hists:
+                A.zero_entries()
+            for Ii in range(m * n):
+                i, j = Ii // n, Ii % n
+                if i > 0: A.set_values([Ii], [Ii - n], [-1.0], P.ADD_VALUES)
+                if i < m - 1: A.set_values([Ii], [Ii + n], [-1.0], P.ADD_VALUES)
+                if j > 0: A.set_values([Ii], [Ii - 1], [-1.0], P.ADD_VALUES)
+                if j < n - 1: A.set_values([Ii], [Ii + 1], [-1.0], P.ADD_VALUES)
+                A.set_values([Ii], [Ii], [dv], P.ADD_VALUES)
+            A.assemble()
+            u, b = A.create_vecs()
+            u.set_array(np.arange(m * n, dtype=float))
+            A.mult(u, b)
+            x = u.duplicate()
+            ksp.set_operators(A)
+            res = ksp.solve(b, x)
+            assert res["its"] == 5
+            hists.append([monitor_short(v) for v in res["history"]])
+            for o in (u, b, x):
+                o.destroy()
+        ksp.destroy(); A.destroy()
+        return hists
+
+    assert run_ranks(1, body)[0] == EX5_1_OUT
+
+
+@pytest.mark.parametrize("size", [1, 2])
+def test_ex10_file_flow(orc, golden_dir, tmp_path, size):
+    """src/ksp/ksp/examples/tutorials/ex10.c:103-147 shape: MatLoad, VecLoad of the right-hand side from the same file, KSPSolve;
+    then VecView/VecLoad round trip."""
+    from petsc_amd import petsc as P
+    g = load(golden_dir, "spd-real-int32-float64")
+    src = os.path.join(golden_dir, "petscbin_spd-real-int32-float64.dat")
+    out = str(tmp_path / ("sol%d.dat" % size))
+
+    def body(comm):
+        A = P.Mat(comm)
+        off = A.load(src)
+        N = A.sizes()[2]
+        b = P.Vec(comm, P.PETSC_DECIDE, N, "hip")
+        b.load(src, off)
+        rs, re = b.ownership_range()
+        np.testing.assert_array_equal(b.array(), g["vec0"][rs:re])
+        x = b.duplicate()
+        ksp = P.KSP(comm, "cg", "jacobi")
+        ksp.set_operators(A)
+        ksp.set_tolerances(rtol=1e-12)
+        res = ksp.solve(b, x)
+        x.view(out)
+        x2 = b.duplicate()
+        x2.load(out)
+        np.testing.assert_array_equal(x2.array(), x.array())
+        res["x"] = x.array()
+        for o in (ksp, x, x2, b, A):
+            o.destroy()
+        return res
+
+    ref = orc.operator(g["i"], g["j"], g["a"], size).solve(g["vec0"], "cg", "jacobi", rtol=1e-12)
+    check_ksp(run_ranks(size, body), ref)
+
+
+def test_jacobi_variants(orc):
+    """PCJacobi rowmax / rowsum / abs / zero diagonal -> 1.0 (jacobi.c:174-195)."""
+    from petsc_amd import petsc as P
+    ai = np.array([0, 2, 4, 5, 7], np.int32)
+    aj = np.array([0, 1, 0, 2, 2, 1, 3], np.int32)
+    aa = np.array([2.0, -1.0, 3.0, 4.0, -5.0, 1.0, 0.0])
+
+    def body(comm):
+        A = P.Mat.seqaij_with_arrays(comm, 4, 4, ai, aj, aa)
+        out = {}
+        for nm, jt, ua in (("diag", P.PC_JACOBI_DIAGONAL, False), ("abs", P.PC_JACOBI_DIAGONAL, True), ("rowmax", P.PC_JACOBI_ROWMAX, False), ("rowsum", P.PC_JACOBI_ROWSUM, False)):
+            ksp = P.KSP(comm, "cg", "jacobi")
+            ksp.set_operators(A)
+            ksp.pc_jacobi_set_type(jt)
+            ksp.pc_jacobi_set_use_abs(ua)
+            x = P.Vec.from_array(comm, np.ones(4))
+            y = x.duplicate()
+            P.chk(P.lib().PCApply(ksp.pc, x.h, y.h))
+            out[nm] = y.array()
+            for o in (ksp, x, y):
+                o.destroy()
+        A.destroy()
+        return out
+
+    r = run_ranks(1, body)[0]
+    np.testing.assert_array_equal(r["diag"], [0.5, 1.0, -0.2, 1.0])  # row 1 has no diagonal entry, row 3 an explicit zero
+    np.testing.assert_array_equal(r["abs"], [0.5, 1.0, 0.2, 1.0])
+    np.testing.assert_array_equal(r["rowmax"], [0.5, 0.25, 0.2, 1.0])
+    np.testing.assert_array_equal(r["rowsum"], [1.0, 1.0 / 7.0, -0.2, 1.0])
+
+
+def test_full_size_properties(orc):
+    """BASELINE config 2 at full size (128^3, 7-point): linearity and symmetry of the SpMV, and agreement with the oracle on
+    a strided sample of rows (the oracle computes only those rows)."""
+    from petsc_amd import generators as G, petsc as P
+    ai, aj, aa = G.laplace3d_7pt(128, dirichlet_rows=False)
+    n = len(ai) - 1
+
+    def body(comm):
+        A = P.Mat.seqaij_with_arrays(comm, n, n, ai, aj, aa)
+        rng = np.random.default_rng(1)
+        xa, xb = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        x, y = A.create_vecs()
+        outs = []
+        for v in (xa, xb, 2.0 * xa - 3.0 * xb):
+            x.set_array(v)
+            A.mult(x, y)
+            outs.append(y.array())
+        ya, yb, yc = outs
+        assert np.abs(yc - (2.0 * ya - 3.0 * yb)).max() <= 1e-12 * np.abs(yc).max()
+        assert abs(xb @ ya - xa @ yb) <= 1e-12 * np.abs(xb * ya).sum()  # symmetric matrix
+        rows = np.arange(0, n, 4099)
+        ref = np.array([np.dot(aa[ai[r]:ai[r + 1]], xa[aj[ai[r]:ai[r + 1]]]) for r in rows])
+        assert np.abs(ya[rows] - ref).max() <= 1e-12 * np.abs(ref).max()
+        d = x.duplicate()
+        A.get_diagonal(d)
+        np.testing.assert_array_equal(d.array(), np.full(n, 6.0))
+        for o in (x, y, d, A):
+            o.destroy()
+        return True
+
+    assert run_ranks(1, body)[0]
