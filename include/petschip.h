@@ -104,6 +104,14 @@ int phip_mat_getdiagonal(phip_mat A, double *d_v);
 /* Row-block plan introspection (tests): number of blocks, nnz capacity per block, threads per row used. */
 int phip_mat_plan_info(phip_mat A, int32_t *nblocks, int32_t *block_nnz_cap, int32_t *threads_per_row, int64_t *nnz);
 int phip_mat_plan_get(phip_mat A, int32_t *h_block_row /* nblocks+1 */);
+/* Device layout.  1 = CSR row blocks (any matrix).  2 = "SELL-dict": 512-row slices stored slot-major with a one-byte index into the
+ * table of distinct diagonals (col - row) in place of the 4-byte column: 9 instead of 12 bytes per nonzero; built at upload when the
+ * matrix has <= 256 distinct diagonals, rows of <= 255 entries and < 15 % slice padding (the stencil matrices of DMDA; the
+ * reference's precedent for a second layout is MatCUSPStorageFormat csr/ell/dia, aijcusp.cu:92-100,171-183).  0 = auto.
+ * Both layouts give the same bits.  phip_set_default_mat_format applies to matrices created afterwards. */
+int phip_set_default_mat_format(int fmt);
+int phip_mat_set_format(phip_mat A, int fmt);
+int phip_mat_format_info(phip_mat A, int *format, int32_t *ndiagonals, int64_t *padded_entries);
 /* tuning: threads_per_row (0 = auto), 1,2,4,...,64 */
 int phip_mat_set_threads_per_row(phip_mat A, int32_t tpr);
 

@@ -17,6 +17,11 @@ struct phip_ctx_s {
   double      *d_partials;  // [PHIP_MAX_MVEC][PHIP_RED_BLOCKS] block partials of reductions
   double      *d_result;    // [PHIP_MAX_MVEC] final reduction results (device)
   double      *h_result;    // pinned host mirror of d_result
+  unsigned int *d_ticket;   // arrival counter of the fused reduction tail (zero between launches)
+  double      *h_slot;      // pinned, device-visible: results published by the last workgroup of a reduction
+  double      *h_slot_dev;  // device address of h_slot
+  unsigned long long *h_seq, *h_seq_dev; // sequence word the host spins on
+  unsigned long long  seq;  // last sequence number issued
   int         *d_flag;      // small int scratch (jacobi zero flag)
   int         *h_flag;      // pinned
   int          prof_on;     // phip_profile_enable: hipEvent pair around every SpMV launch
@@ -24,6 +29,9 @@ struct phip_ctx_s {
 };
 
 /* profiling records (phip_runtime.hip): kind 0 = MatMult launches, 1 = MatMultAdd launches */
+/* wait until the device has published sequence number seq into c->h_seq (spin, with a periodic stream health check) */
+int phip_wait_seq(phip_ctx c, unsigned long long seq);
+
 int phip_prof_open(phip_ctx c, int kind, hipEvent_t *start, hipEvent_t *stop);
 
 void phip_set_error(const char *fmt, ...);

@@ -50,6 +50,13 @@ extern "C" int phip_init(int device, phip_ctx *out)
   PHIP_CHECK_HIP(hipMalloc((void **)&c->d_partials, sizeof(double) * PHIP_MAX_MVEC * PHIP_RED_BLOCKS));
   PHIP_CHECK_HIP(hipMalloc((void **)&c->d_result, sizeof(double) * PHIP_MAX_MVEC));
   PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_result, sizeof(double) * PHIP_MAX_MVEC, hipHostMallocDefault));
+  PHIP_CHECK_HIP(hipMalloc((void **)&c->d_ticket, 8192));
+  PHIP_CHECK_HIP(hipMemsetAsync(c->d_ticket, 0, 8192, c->stream));
+  PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_slot, sizeof(double) * PHIP_MAX_MVEC, hipHostMallocMapped | hipHostMallocCoherent));
+  PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_seq, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  PHIP_CHECK_HIP(hipHostGetDevicePointer((void **)&c->h_slot_dev, c->h_slot, 0));
+  PHIP_CHECK_HIP(hipHostGetDevicePointer((void **)&c->h_seq_dev, c->h_seq, 0));
+  *c->h_seq = 0; c->seq = 0;
   PHIP_CHECK_HIP(hipMalloc((void **)&c->d_flag, sizeof(int) * 16));
   PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_flag, sizeof(int) * 16, hipHostMallocDefault));
   PHIP_CHECK_HIP(hipMemsetAsync(c->d_flag, 0, sizeof(int) * 16, c->stream));
@@ -65,6 +72,7 @@ extern "C" int phip_finalize(phip_ctx c)
   PHIP_CHECK_HIP(hipSetDevice(c->device));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->comm_stream));
+  hipFree(c->d_ticket); hipHostFree(c->h_slot); hipHostFree(c->h_seq);
   hipFree(c->d_partials); hipFree(c->d_result); hipHostFree(c->h_result); hipFree(c->d_flag); hipHostFree(c->h_flag);
   if (c->prof) {
     for (int k = 0; k < 2; k++) for (int w = 0; w < 2; w++) for (hipEvent_t e : c->prof->ev[k][w]) hipEventDestroy(e);
@@ -157,14 +165,48 @@ extern "C" int phip_device_sync(phip_ctx c)
 
 extern "C" void *phip_stream(phip_ctx c) { return c ? (void *)c->stream : NULL; }
 
+/* copy n device scalars into the pinned slot and raise the sequence word: one tiny kernel instead of a copy + stream sync */
+__global__ void publish_kernel(const double *__restrict__ src, int n, double *slot, unsigned long long *seqw, unsigned long long seq)
+{
+  const int t = threadIdx.x;
+  if (t < n) slot[t] = src[t];
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(seqw, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int phip_wait_seq(phip_ctx c, unsigned long long seq)
+{
+  volatile unsigned long long *p = c->h_seq;
+  for (unsigned long spin = 1;; spin++) {
+    if (*p == seq) break;
+    if ((spin & 0x3FFF) == 0) { /* every ~16k polls: is the stream still healthy? */
+      hipError_t e = hipStreamQuery(c->stream);
+      if (e == hipSuccess) {
+        if (*p == seq) break;
+        phip_set_error("phip_wait_seq: the stream drained but result %llu was never published (have %llu)", seq, (unsigned long long)*p);
+        return PHIP_ERR_LIB;
+      }
+      if (e != hipErrorNotReady) { phip_set_error("phip_wait_seq: %s", hipGetErrorString(e)); return PHIP_ERR_LIB; }
+    }
+    __builtin_ia32_pause();
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return 0;
+}
+
 extern "C" int phip_read_scalars(phip_ctx c, const double *d_src, int32_t n, double *h_dst)
 {
   PHIP_REQUIRE(c && h_dst, PHIP_ERR_ARG_NULL, "phip_read_scalars: null argument");
   PHIP_REQUIRE(n >= 0 && n <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_read_scalars: n=%d", n);
   PHIP_NEED_DEVICE(c, "phip_read_scalars");
-  if (n) PHIP_CHECK_HIP(hipMemcpyAsync(c->h_result, d_src, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
-  for (int i = 0; i < n; i++) h_dst[i] = c->h_result[i];
+  if (!n) { PHIP_CHECK_HIP(hipStreamSynchronize(c->stream)); return 0; }
+  const unsigned long long seq = ++c->seq;
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(PHIP_MAX_MVEC), 0, c->stream, d_src, n, c->h_slot_dev, c->h_seq_dev, seq);
+  PHIP_CHECK_HIP(hipGetLastError());
+  int rc = phip_wait_seq(c, seq);
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) h_dst[i] = c->h_slot[i];
   return 0;
 }
 

@@ -16,6 +16,16 @@
 //            (src/mat/impls/aij/seq/aij.h:409-411) compiled without FMA contraction, bit for bit.
 //   A row with more than SPMV_CAP nonzeros gets a block of its own and is reduced by the whole workgroup straight from HBM.
 // Roofline: HBM.  Algorithmic bytes per launch: 12*nz + 20*m + 4 (MultAdd: + 8*m).
+//
+// Second layout, chosen at upload when the matrix is stencil-like ("SELL-dict"): the set of distinct diagonals col-row has at most
+// 256 members, no row has more than 255 entries and slice padding costs < 15 %.  Rows are cut into slices of 512; inside a slice the
+// entries are stored slot-major (entry s of every row, then entry s+1, ...), values as f64 and the column as a ONE-BYTE index into the
+// diagonal table, so a nonzero costs 9 bytes of HBM traffic instead of 12:
+//   sval[P] f64, scode[P] uint8 (P = padded entries), slen[m] uint8 row lengths, sptr[S+1] int64 slice offsets, soffs[<=256] int32
+// Kernel: one 256-thread workgroup per slice, each lane owns two adjacent rows (16-byte value loads, 2-byte code loads, all fully
+// coalesced), looks the diagonals up in LDS, gathers x[row + diag] and accumulates ITS rows k-ascending from 0.0 (or y[i]) with
+// separately rounded multiply and add: again the arithmetic of PetscSparseDensePlusDot bit for bit.  The CSR arrays stay on the
+// device for MatGetDiagonal and as the source of truth.
 #include "phip_internal.h"
 #include <stdlib.h>
 #include <vector>
@@ -23,6 +33,11 @@
 #define SPMV_CAP 2046          /* nonzeros per row block; +2 alignment slack = 2048 LDS doubles = 16 KiB */
 #define SPMV_PAIRS 1024        /* (SPMV_CAP + 2) / 2 */
 #define SPMV_ROWS_MAX 256      /* rows per block */
+#define SELL_H 512             /* rows per SELL slice = 2 rows per lane */
+#define SELL_MAX_OFFS 256
+#define SELL_MAX_PAD 1.15
+
+static int g_default_fmt = 0; /* phip_set_default_mat_format */
 
 struct phip_mat_s {
   phip_ctx ctx;
@@ -38,6 +53,16 @@ struct phip_mat_s {
   int32_t  tpr_user;
   std::vector<int32_t> *h_rowptr, *h_blkrow;
   std::vector<uint8_t> *h_blktpr;
+  /* SELL-dict layout (stencil-like matrices) */
+  int      fmt_user;   /* 0 auto, 1 CSR row blocks, 2 SELL-dict (error if not eligible) */
+  int      sell_on, sell_built;
+  int32_t  sell_nslices, sell_noffs;
+  int64_t  sell_padded;
+  double  *d_sval;
+  uint8_t *d_scode, *d_slen;
+  int64_t *d_sptr;
+  int32_t *d_soffs;
+  std::vector<int64_t> *h_sptr;
 };
 
 template <int TPR>
@@ -143,6 +168,57 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(const int32
   }
 }
 
+
+/* SELL-dict SpMV: see the header comment.  Lane t of slice b owns rows 512 b + 2 t and + 1. */
+__global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int32_t n, const int64_t *__restrict__ sptr, const uint8_t *__restrict__ slen,
+                                                                 const double *__restrict__ sval, const uint8_t *__restrict__ scode,
+                                                                 const int32_t *__restrict__ soffs, int noffs, const double *__restrict__ x,
+                                                                 const double *__restrict__ yin, double *__restrict__ yout, int add)
+{
+#pragma clang fp contract(off) /* multiply and add round separately, as the reference's compiled loop does (no FMA) */
+  __shared__ int32_t offs[SELL_MAX_OFFS];
+  const int t = threadIdx.x;
+  offs[t] = (t < noffs) ? soffs[t] : 0;
+  __syncthreads();
+  const int r0 = blockIdx.x * SELL_H + 2 * t;
+  if (r0 >= m) return;
+  const bool has1 = r0 + 1 < m;
+  const int  l0 = slen[r0], l1 = has1 ? slen[r0 + 1] : 0;
+  const int  lm = l0 > l1 ? l0 : l1;
+  const int64_t  base = sptr[blockIdx.x];
+  const double2 *vp = reinterpret_cast<const double2 *>(sval + base) + t;
+  const uchar2  *cp = reinterpret_cast<const uchar2 *>(scode + base) + t;
+  double s0 = 0.0, s1 = 0.0;
+  if (add) { s0 = yin[r0]; if (has1) s1 = yin[r0 + 1]; }
+  int s = 0;
+  for (; s + 4 <= lm; s += 4) {
+    double2 v[4];
+    uchar2  c[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { v[u] = vp[(size_t)(s + u) * (SELL_H / 2)]; c[u] = cp[(size_t)(s + u) * (SELL_H / 2)]; }
+    double xa[4], xb[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bool a0 = s + u < l0, a1 = s + u < l1;
+      xa[u] = x[a0 ? r0 + offs[c[u].x] : 0];
+      xb[u] = x[a1 ? r0 + 1 + offs[c[u].y] : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (s + u < l0) s0 = s0 + v[u].x * xa[u];
+      if (s + u < l1) s1 = s1 + v[u].y * xb[u];
+    }
+  }
+  for (; s < lm; s++) {
+    const double2 v = vp[(size_t)s * (SELL_H / 2)];
+    const uchar2  c = cp[(size_t)s * (SELL_H / 2)];
+    if (s < l0) s0 = s0 + v.x * x[r0 + offs[c.x]];
+    if (s < l1) s1 = s1 + v.y * x[r0 + 1 + offs[c.y]];
+  }
+  if (has1) *reinterpret_cast<double2 *>(yout + r0) = make_double2(s0, s1);
+  else yout[r0] = s0;
+}
+
 __global__ void getdiag_kernel(int32_t m, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx, int32_t R,
                                const int32_t *__restrict__ col, const double *__restrict__ val, double *__restrict__ v, int cprow)
 {
@@ -196,6 +272,118 @@ static void build_plan(const std::vector<int32_t> &rp, int32_t R, int32_t tpr_us
   }
 }
 
+
+/* ---- host: SELL-dict layout --------------------------------------------------------------------- */
+/* Decide eligibility and build sval/scode/slen/sptr/soffs from the host CSR.  Returns 1 when built, 0 when not eligible. */
+static int build_sell(const std::vector<int32_t> &rp, int32_t m, int32_t n, const int32_t *cj, const double *ca, std::vector<int64_t> &sptr,
+                      std::vector<uint8_t> &slen, std::vector<int32_t> &soffs, std::vector<double> *sval, std::vector<uint8_t> &scode)
+{
+  if (m <= 0 || n <= 0) return 0;
+  const int64_t nnz = rp[(size_t)m];
+  if (nnz == 0) return 0;
+  const int32_t S = (m + SELL_H - 1) / SELL_H;
+  sptr.assign((size_t)S + 1, 0);
+  slen.assign((size_t)S * SELL_H + 2, 0);
+  for (int32_t b = 0; b < S; b++) {
+    int L = 0;
+    for (int32_t r = b * SELL_H; r < m && r < (b + 1) * SELL_H; r++) {
+      const int len = rp[(size_t)r + 1] - rp[(size_t)r];
+      if (len > 255) return 0;
+      slen[(size_t)r] = (uint8_t)len;
+      if (len > L) L = len;
+    }
+    sptr[(size_t)b + 1] = sptr[(size_t)b] + (int64_t)L * SELL_H;
+  }
+  const int64_t P = sptr[(size_t)S];
+  if ((double)P > SELL_MAX_PAD * (double)nnz + SELL_H * 8) return 0;
+  scode.assign((size_t)P + 16, 0);
+  if (sval) sval->assign((size_t)P + 16, 0.0);
+  soffs.clear();
+  uint8_t guess[256];
+  memset(guess, 0, sizeof(guess));
+  for (int32_t b = 0; b < S; b++) {
+    for (int32_t r = b * SELL_H; r < m && r < (b + 1) * SELL_H; r++) {
+      const int32_t k0 = rp[(size_t)r];
+      const int     len = rp[(size_t)r + 1] - k0;
+      const int64_t pos0 = sptr[(size_t)b] + (r - b * SELL_H);
+      for (int sl = 0; sl < len; sl++) {
+        const int32_t d = cj[k0 + sl] - r;
+        int           code = guess[sl];
+        if (code >= (int)soffs.size() || soffs[(size_t)code] != d) {
+          code = -1;
+          for (size_t q = 0; q < soffs.size(); q++) if (soffs[q] == d) { code = (int)q; break; }
+          if (code < 0) {
+            if (soffs.size() >= SELL_MAX_OFFS) return 0;
+            code = (int)soffs.size();
+            soffs.push_back(d);
+          }
+          guess[sl] = (uint8_t)code;
+        }
+        scode[(size_t)(pos0 + (int64_t)sl * SELL_H)] = (uint8_t)code;
+        if (sval) (*sval)[(size_t)(pos0 + (int64_t)sl * SELL_H)] = ca[k0 + sl];
+      }
+    }
+  }
+  return 1;
+}
+
+static void fill_sell_values(const std::vector<int32_t> &rp, int32_t m, const double *ca, const std::vector<int64_t> &sptr, std::vector<double> &sval)
+{
+  const int32_t S = (m + SELL_H - 1) / SELL_H;
+  sval.assign((size_t)sptr[(size_t)S] + 16, 0.0);
+  for (int32_t b = 0; b < S; b++)
+    for (int32_t r = b * SELL_H; r < m && r < (b + 1) * SELL_H; r++) {
+      const int32_t k0 = rp[(size_t)r];
+      const int     len = rp[(size_t)r + 1] - k0;
+      const int64_t pos0 = sptr[(size_t)b] + (r - b * SELL_H);
+      for (int sl = 0; sl < len; sl++) sval[(size_t)(pos0 + (int64_t)sl * SELL_H)] = ca[k0 + sl];
+    }
+}
+
+static void free_sell(phip_mat A)
+{
+  if (A->ctx->device >= 0) { hipFree(A->d_sval); hipFree(A->d_scode); hipFree(A->d_slen); hipFree(A->d_sptr); hipFree(A->d_soffs); }
+  A->d_sval = NULL; A->d_scode = NULL; A->d_slen = NULL; A->d_sptr = NULL; A->d_soffs = NULL;
+  A->sell_on = 0; A->sell_built = 0;
+}
+
+/* (re)build the SELL-dict copy according to fmt_user; h_j/h_a = host CSR */
+static int setup_sell(phip_mat A, const int32_t *h_j, const double *h_a)
+{
+  free_sell(A);
+  if (A->fmt_user == 1 || A->use_cprow) {
+    PHIP_REQUIRE(A->fmt_user != 2, PHIP_ERR_SUP, "phip_mat: the SELL-dict layout does not apply to compressed-row matrices");
+    return 0;
+  }
+  std::vector<uint8_t> slen, scode;
+  std::vector<int32_t> soffs;
+  std::vector<double>  sval;
+  const int ok = build_sell(*A->h_rowptr, A->m, A->n, h_j, h_a, *A->h_sptr, slen, soffs, &sval, scode);
+  if (!ok) {
+    PHIP_REQUIRE(A->fmt_user != 2, PHIP_ERR_SUP, "phip_mat: matrix is not eligible for the SELL-dict layout (more than %d distinct diagonals, a row longer than 255, or padding above %.0f %%)", SELL_MAX_OFFS, (SELL_MAX_PAD - 1) * 100);
+    return 0;
+  }
+  A->sell_nslices = (A->m + SELL_H - 1) / SELL_H;
+  A->sell_noffs = (int32_t)soffs.size();
+  A->sell_padded = (*A->h_sptr)[(size_t)A->sell_nslices];
+  A->sell_on = 1; A->sell_built = 1;
+  if (A->ctx->device < 0) return 0;
+  hipStream_t st = A->ctx->stream;
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_sval, sizeof(double) * sval.size()));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_scode, scode.size()));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_slen, slen.size()));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_sptr, sizeof(int64_t) * A->h_sptr->size()));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_soffs, sizeof(int32_t) * SELL_MAX_OFFS));
+  soffs.resize(SELL_MAX_OFFS, 0);
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_sval, sval.data(), sizeof(double) * sval.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_scode, scode.data(), scode.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_slen, slen.data(), slen.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_sptr, A->h_sptr->data(), sizeof(int64_t) * A->h_sptr->size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_soffs, soffs.data(), sizeof(int32_t) * SELL_MAX_OFFS, hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
 static int upload_plan(phip_mat A)
 {
   build_plan(*A->h_rowptr, A->R, A->tpr_user, *A->h_blkrow, *A->h_blktpr);
@@ -231,6 +419,8 @@ extern "C" int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t
   A->h_rowptr = new std::vector<int32_t>((size_t)A->R + 1);
   A->h_blkrow = new std::vector<int32_t>();
   A->h_blktpr = new std::vector<uint8_t>();
+  A->h_sptr = new std::vector<int64_t>();
+  A->fmt_user = g_default_fmt;
   const int32_t *rp = use_cprow ? h_cprow_i : h_i;
   for (int32_t r = 0; r <= A->R; r++) (*A->h_rowptr)[r] = rp[r];
   if (use_cprow) {
@@ -241,6 +431,7 @@ extern "C" int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t
   if (ctx->device < 0) { /* planning-only: no device copy */
     int prc = upload_plan(A);
     if (prc) return prc;
+    if ((prc = setup_sell(A, h_j, h_a))) return prc;
     *out = A;
     return 0;
   }
@@ -261,6 +452,7 @@ extern "C" int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t
   PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   int rc = upload_plan(A);
   if (rc) return rc;
+  if ((rc = setup_sell(A, h_j, h_a))) return rc;
   *out = A;
   return 0;
 }
@@ -271,6 +463,13 @@ extern "C" int phip_mat_update_values(phip_mat A, const double *h_a)
   if (A->ctx->device < 0) return 0;
   PHIP_CHECK_HIP(hipSetDevice(A->ctx->device));
   if (A->nnz) PHIP_CHECK_HIP(hipMemcpyAsync(A->d_val, h_a, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice, A->ctx->stream));
+  if (A->sell_built) {
+    std::vector<double> sval;
+    fill_sell_values(*A->h_rowptr, A->m, h_a, *A->h_sptr, sval);
+    PHIP_CHECK_HIP(hipMemcpyAsync(A->d_sval, sval.data(), sizeof(double) * sval.size(), hipMemcpyHostToDevice, A->ctx->stream));
+    PHIP_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
+    return 0;
+  }
   PHIP_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
   return 0;
 }
@@ -278,9 +477,11 @@ extern "C" int phip_mat_update_values(phip_mat A, const double *h_a)
 extern "C" int phip_mat_destroy(phip_mat A)
 {
   if (!A) return 0;
-  if (A->ctx->device < 0) { delete A->h_rowptr; delete A->h_blkrow; delete A->h_blktpr; delete A; return 0; }
+  if (A->ctx->device < 0) { delete A->h_rowptr; delete A->h_blkrow; delete A->h_blktpr; delete A->h_sptr; delete A; return 0; }
   hipSetDevice(A->ctx->device);
   hipStreamSynchronize(A->ctx->stream);
+  free_sell(A);
+  delete A->h_sptr;
   hipFree(A->d_rowptr); hipFree(A->d_ridx); hipFree(A->d_col); hipFree(A->d_val); hipFree(A->d_blkrow); hipFree(A->d_blktpr);
   delete A->h_rowptr; delete A->h_blkrow; delete A->h_blktpr;
   delete A;
@@ -296,8 +497,12 @@ static int launch_spmv(phip_mat A, const double *d_x, const double *d_yin, doubl
     if (rc) return rc;
     PHIP_CHECK_HIP(hipEventRecord(e0, A->ctx->stream));
   }
-  hipLaunchKernelGGL(spmv_rowblock_kernel, dim3((unsigned)A->nblocks), dim3(PHIP_THREADS), 0, A->ctx->stream, A->d_blkrow, A->d_blktpr, A->d_rowptr,
-                     A->d_ridx, A->d_col, A->d_val, d_x, d_yin, d_yout, add, A->use_cprow);
+  if (A->sell_on)
+    hipLaunchKernelGGL(spmv_sell_kernel, dim3((unsigned)A->sell_nslices), dim3(PHIP_THREADS), 0, A->ctx->stream, A->m, A->n, A->d_sptr, A->d_slen, A->d_sval,
+                       A->d_scode, A->d_soffs, A->sell_noffs, d_x, d_yin, d_yout, add);
+  else
+    hipLaunchKernelGGL(spmv_rowblock_kernel, dim3((unsigned)A->nblocks), dim3(PHIP_THREADS), 0, A->ctx->stream, A->d_blkrow, A->d_blktpr, A->d_rowptr,
+                       A->d_ridx, A->d_col, A->d_val, d_x, d_yin, d_yout, add, A->use_cprow);
   PHIP_CHECK_HIP(hipGetLastError());
   if (e1) PHIP_CHECK_HIP(hipEventRecord(e1, A->ctx->stream));
   return 0;
@@ -359,4 +564,31 @@ extern "C" int phip_mat_set_threads_per_row(phip_mat A, int32_t tpr)
   PHIP_REQUIRE(tpr >= 0 && tpr <= 64 && (tpr & (tpr - 1)) == 0, PHIP_ERR_ARG_OUTOFRANGE, "threads per row must be 0 or a power of two <= 64, got %d", tpr);
   A->tpr_user = tpr;
   return upload_plan(A);
+}
+
+/* layout choice: 0 auto (SELL-dict when eligible), 1 CSR row blocks, 2 SELL-dict or fail.  The default applies to matrices created
+   afterwards; phip_mat_set_format switches an existing matrix between the layouts that were built for it. */
+extern "C" int phip_set_default_mat_format(int fmt)
+{
+  PHIP_REQUIRE(fmt >= 0 && fmt <= 2, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_default_mat_format: %d", fmt);
+  g_default_fmt = fmt;
+  return 0;
+}
+
+extern "C" int phip_mat_set_format(phip_mat A, int fmt)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_set_format: null matrix");
+  PHIP_REQUIRE(fmt >= 0 && fmt <= 2, PHIP_ERR_ARG_OUTOFRANGE, "phip_mat_set_format: %d", fmt);
+  PHIP_REQUIRE(fmt != 2 || A->sell_built, PHIP_ERR_SUP, "phip_mat_set_format: no SELL-dict copy was built for this matrix");
+  A->sell_on = (fmt != 1 && A->sell_built) ? 1 : 0;
+  return 0;
+}
+
+extern "C" int phip_mat_format_info(phip_mat A, int *format, int32_t *ndiagonals, int64_t *padded_entries)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_format_info: null matrix");
+  if (format) *format = A->sell_on ? 2 : 1;
+  if (ndiagonals) *ndiagonals = A->sell_built ? A->sell_noffs : 0;
+  if (padded_entries) *padded_entries = A->sell_built ? A->sell_padded : 0;
+  return 0;
 }

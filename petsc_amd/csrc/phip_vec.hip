@@ -4,7 +4,11 @@
 // Algorithmic bytes: dot 16n, norm 8n, axpy/aypx/pointwise 24n, waxpy 24n, scale 16n, copy 16n, set 8n,
 // mdot(nv) 8n(nv+1), maxpy(nv) 8n(nv+2).
 // Reductions: fixed grid of PHIP_RED_BLOCKS workgroups; wavefront (64-lane) shuffle reduction -> LDS across the 4 waves ->
-// one partial per workgroup; a second single-workgroup kernel sums the partials in a fixed order (deterministic for a given n).
+// one partial per workgroup, stored write-through (sc1); the workgroup whose arrival ticket is last sums the partials in a
+// fixed order (deterministic for a given n, whichever workgroup that is), writes the result to device memory and, for the calls
+// that return a host scalar, into a pinned slot followed by a sequence word the host spins on: one launch per reduction,
+// no second kernel, no copy, no stream synchronisation.  Hand-off form: MI355X_MICROARCH.md "Hand-offs measured with sc1 loads"
+// row 1 (one lane per workgroup stores sc1, drains vmcnt, adds to an agent-scope counter; the last arriver loads sc1).
 #include "phip_internal.h"
 
 #define MV_MAX 8 /* vectors fused per mdot/maxpy launch */
@@ -12,6 +16,18 @@
 struct MVPack {
   const double *y[MV_MAX];
   double        a[MV_MAX];
+};
+
+/* where a reduction launch leaves its results */
+struct RedCtl {
+  double             *partial; /* [PHIP_MAX_MVEC][PHIP_RED_BLOCKS] */
+  unsigned int       *ticket;  /* arrival counters [33][32] (one used word per 128-byte line), zero on entry and on exit */
+  double             *d_out;   /* device results, indexed like the partial rows */
+  double             *h_slot;  /* pinned host slot (device address) or NULL: publish d_out[0..npub) there ... */
+  unsigned long long *h_seq;   /* ... then store seq here */
+  unsigned long long  seq;
+  int                 npub;
+  int                 kofs;    /* first partial row / d_out index of this launch */
 };
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -45,9 +61,86 @@ __device__ __forceinline__ void block_sum(double (&acc)[NV], double *lds /* [4*N
   }
 }
 
+/* Tail of every reduction kernel.  acc[] holds the workgroup's partials in thread 0.  MODE 0: NV sums.  MODE 1: acc[0] = max,
+   acc[1] = NaN flag -> one result (NaN if any flag, bvec2.c:253-258). */
+template <int NV, int MODE>
+__device__ __forceinline__ void reduce_tail(double (&acc)[NV], double *lds /* >= 4 doubles */, const RedCtl c)
+{
+  __shared__ int s_last;
+  const int      t = threadIdx.x;
+  const int      nb = gridDim.x;
+  if (t == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) __hip_atomic_store(&c.partial[(size_t)(c.kofs + k) * PHIP_RED_BLOCKS + blockIdx.x], acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    /* two-level arrival count: 32 workgroups per group counter (each on a 128-byte line of its own), then one top counter, so that
+       no word takes more than 32 serialised atomics (~12 ns each on one address); the last arrivers put the counters back to zero */
+    const int          g = blockIdx.x >> 5;
+    const unsigned int gsize = (unsigned int)((nb - (g << 5)) < 32 ? (nb - (g << 5)) : 32);
+    int                last = 0;
+    const unsigned int tk = __hip_atomic_fetch_add(&c.ticket[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == gsize - 1) {
+      __hip_atomic_store(&c.ticket[g * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int ngroups = (unsigned int)((nb + 31) >> 5);
+      const unsigned int tk2 = __hip_atomic_fetch_add(&c.ticket[32 * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tk2 == ngroups - 1) {
+        __hip_atomic_store(&c.ticket[32 * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = 1;
+      }
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  /* last workgroup: wave w sums partial rows w, w+4, ...: 16 values per lane in index order, then the 64-lane tree (a fixed order
+     for a given grid, whichever workgroup arrives last); all of a row's loads are in flight at once */
+  const int w = t >> 6, lane = t & 63;
+  if (MODE == 1) {
+    if (w == 0) {
+      double m = 0.0, f = 0.0;
+#pragma unroll
+      for (int j = 0; j < PHIP_RED_BLOCKS / 64; j++) {
+        const int i = lane + 64 * j;
+        if (i < nb) {
+          m = fmax(m, __hip_atomic_load(&c.partial[(size_t)c.kofs * PHIP_RED_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          f = fmax(f, __hip_atomic_load(&c.partial[(size_t)(c.kofs + 1) * PHIP_RED_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+      }
+      m = wave_max(m); f = wave_max(f);
+      if (lane == 0) c.d_out[c.kofs] = (f > 0.0) ? __builtin_nan("") : m;
+    }
+  } else {
+    for (int k = w; k < NV; k += PHIP_THREADS / 64) {
+      const double *row = c.partial + (size_t)(c.kofs + k) * PHIP_RED_BLOCKS;
+      double        v[PHIP_RED_BLOCKS / 64];
+#pragma unroll
+      for (int j = 0; j < PHIP_RED_BLOCKS / 64; j++) {
+        const int i = lane + 64 * j;
+        v[j] = (i < nb) ? __hip_atomic_load(&row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < PHIP_RED_BLOCKS / 64; j++) s += v[j];
+      s = wave_sum(s);
+      if (lane == 0) c.d_out[c.kofs + k] = s;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) {
+    if (c.h_slot) {
+      /* d_out[0..kofs) came from earlier launches of the same call (earlier kernels on this stream), the rest from the stores above */
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int k = 0; k < c.npub; k++) c.h_slot[k] = __hip_atomic_load(&c.d_out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(c.h_seq, c.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 /* z[k] = sum_i x_i * y_k,i  for k < NV : x is read once per launch.  partial layout: [k][block] */
 template <int NV>
-__global__ __launch_bounds__(PHIP_THREADS) void mdot_kernel(int32_t n, const double *__restrict__ x, MVPack P, double *__restrict__ partial, int kofs)
+__global__ __launch_bounds__(PHIP_THREADS) void mdot_kernel(int32_t n, const double *__restrict__ x, MVPack P, RedCtl ctl)
 {
   __shared__ double lds[4 * NV];
   double            acc[NV];
@@ -68,15 +161,12 @@ __global__ __launch_bounds__(PHIP_THREADS) void mdot_kernel(int32_t n, const dou
     for (int k = 0; k < NV; k++) acc[k] += x[n - 1] * P.y[k][n - 1];
   }
   block_sum<NV>(acc, lds);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < NV; k++) partial[(size_t)(kofs + k) * PHIP_RED_BLOCKS + blockIdx.x] = acc[k];
-  }
+  reduce_tail<NV, 0>(acc, lds, ctl);
 }
 
 /* kind 1: sum x^2 ; 2: sum |x| ; 3: max |x| with NaN propagation (bvec2.c:253-258) ; 4: {sum |x|, sum x^2} */
 template <int KIND>
-__global__ __launch_bounds__(PHIP_THREADS) void norm_kernel(int32_t n, const double *__restrict__ x, double *__restrict__ partial)
+__global__ __launch_bounds__(PHIP_THREADS) void norm_kernel(int32_t n, const double *__restrict__ x, RedCtl ctl)
 {
   __shared__ double lds[8];
   double            acc[2] = {0.0, 0.0};
@@ -100,45 +190,20 @@ __global__ __launch_bounds__(PHIP_THREADS) void norm_kernel(int32_t n, const dou
     if ((threadIdx.x & 63) == 0) { lds[threadIdx.x >> 6] = m; lds[4 + (threadIdx.x >> 6)] = f; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      m = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
-      f = fmax(fmax(lds[4], lds[5]), fmax(lds[6], lds[7]));
-      partial[blockIdx.x] = m;
-      partial[PHIP_RED_BLOCKS + blockIdx.x] = f;
+      acc[0] = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
+      acc[1] = fmax(fmax(lds[4], lds[5]), fmax(lds[6], lds[7]));
     }
-  } else {
+    __syncthreads();
+    reduce_tail<2, 1>(acc, lds, ctl);
+  } else if (KIND == 4) {
     block_sum<2>(acc, lds);
-    if (threadIdx.x == 0) {
-      partial[blockIdx.x] = acc[0];
-      partial[PHIP_RED_BLOCKS + blockIdx.x] = acc[1];
-    }
-  }
-}
-
-/* final pass: out[k] = combine(partial[k][0..nb)) ; mode 0 sum, 1 max-with-nan-flag (k=0 value, k=1 flag) */
-__global__ __launch_bounds__(PHIP_THREADS) void finalize_kernel(int nb, int nv, const double *__restrict__ partial, double *__restrict__ out, int mode)
-{
-  __shared__ double lds[8];
-  if (mode == 1) {
-    double m = 0.0, f = 0.0;
-    for (int i = threadIdx.x; i < nb; i += PHIP_THREADS) { m = fmax(m, partial[i]); f = fmax(f, partial[PHIP_RED_BLOCKS + i]); }
-    m = wave_max(m); f = wave_max(f);
-    if ((threadIdx.x & 63) == 0) { lds[threadIdx.x >> 6] = m; lds[4 + (threadIdx.x >> 6)] = f; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      m = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
-      f = fmax(fmax(lds[4], lds[5]), fmax(lds[6], lds[7]));
-      out[0] = (f > 0.0) ? __builtin_nan("") : m;
-    }
-    return;
-  }
-  for (int k = 0; k < nv; k++) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nb; i += PHIP_THREADS) s += partial[(size_t)k * PHIP_RED_BLOCKS + i];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    reduce_tail<2, 0>(acc, lds, ctl);
+  } else {
+    double a1[1] = {acc[0]};
+    block_sum<1>(a1, lds);
     __syncthreads();
-    if (threadIdx.x == 0) out[k] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
-    __syncthreads();
+    reduce_tail<1, 0>(a1, lds, ctl);
   }
 }
 
@@ -366,18 +431,20 @@ extern "C" int phip_jacobi_setup(phip_ctx c, int32_t n, double *d_diag, int usea
 }
 
 template <int NV>
-static void launch_mdot(phip_ctx c, int32_t n, const double *d_x, const MVPack &P, int kofs, int grid)
+static void launch_mdot(phip_ctx c, int32_t n, const double *d_x, const MVPack &P, const RedCtl &ctl, int grid)
 {
-  hipLaunchKernelGGL((mdot_kernel<NV>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, P, c->d_partials, kofs);
+  hipLaunchKernelGGL((mdot_kernel<NV>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, P, ctl);
 }
 
 static int reduce_grid(int32_t n) { return phip_grid_for((int64_t)n / 2 + 1, 4, PHIP_RED_BLOCKS); }
 
-extern "C" int phip_vec_reduce_local(phip_ctx c, int kind, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *d_out)
+/* One reduction: results into d_out[0..nres); when publish != 0 also into the pinned slot, with sequence number *seq_out */
+static int reduce_launch(phip_ctx c, int kind, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *d_out, int publish,
+                         unsigned long long *seq_out)
 {
-  CHECK_CTX(c, "phip_vec_reduce_local"); CHECK_N(n, "phip_vec_reduce_local");
-  PHIP_REQUIRE(d_out, PHIP_ERR_ARG_NULL, "phip_vec_reduce_local: null output");
   const int grid = reduce_grid(n);
+  RedCtl    ctl;
+  ctl.partial = c->d_partials; ctl.ticket = c->d_ticket; ctl.d_out = d_out; ctl.h_slot = NULL; ctl.h_seq = NULL; ctl.seq = 0; ctl.npub = 0; ctl.kofs = 0;
   if (kind == 0) {
     PHIP_REQUIRE(nv >= 0 && nv <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_reduce_local: nv=%d (max %d)", nv, PHIP_MAX_MVEC);
     PHIP_REQUIRE(h_dy || !nv, PHIP_ERR_ARG_NULL, "phip_vec_reduce_local: null vector list");
@@ -385,79 +452,85 @@ extern "C" int phip_vec_reduce_local(phip_ctx c, int kind, int32_t n, const doub
       const int g = (nv - k0 < MV_MAX) ? nv - k0 : MV_MAX;
       MVPack    P;
       for (int k = 0; k < MV_MAX; k++) { P.y[k] = (k < g) ? h_dy[k0 + k] : d_x; P.a[k] = 0.0; }
+      ctl.kofs = k0;
+      if (publish && k0 + g == nv) { ctl.h_slot = c->h_slot_dev; ctl.h_seq = c->h_seq_dev; ctl.seq = ++c->seq; ctl.npub = nv; *seq_out = ctl.seq; }
       switch (g) {
-      case 1: launch_mdot<1>(c, n, d_x, P, k0, grid); break;
-      case 2: launch_mdot<2>(c, n, d_x, P, k0, grid); break;
-      case 3: launch_mdot<3>(c, n, d_x, P, k0, grid); break;
-      case 4: launch_mdot<4>(c, n, d_x, P, k0, grid); break;
-      case 5: launch_mdot<5>(c, n, d_x, P, k0, grid); break;
-      case 6: launch_mdot<6>(c, n, d_x, P, k0, grid); break;
-      case 7: launch_mdot<7>(c, n, d_x, P, k0, grid); break;
-      default: launch_mdot<8>(c, n, d_x, P, k0, grid); break;
+      case 1: launch_mdot<1>(c, n, d_x, P, ctl, grid); break;
+      case 2: launch_mdot<2>(c, n, d_x, P, ctl, grid); break;
+      case 3: launch_mdot<3>(c, n, d_x, P, ctl, grid); break;
+      case 4: launch_mdot<4>(c, n, d_x, P, ctl, grid); break;
+      case 5: launch_mdot<5>(c, n, d_x, P, ctl, grid); break;
+      case 6: launch_mdot<6>(c, n, d_x, P, ctl, grid); break;
+      case 7: launch_mdot<7>(c, n, d_x, P, ctl, grid); break;
+      default: launch_mdot<8>(c, n, d_x, P, ctl, grid); break;
       }
-      PHIP_CHECK_HIP(hipGetLastError());
-    }
-    if (nv) {
-      hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(PHIP_THREADS), 0, c->stream, grid, nv, c->d_partials, d_out, 0);
       PHIP_CHECK_HIP(hipGetLastError());
     }
     return 0;
   }
+  if (publish) { ctl.h_slot = c->h_slot_dev; ctl.h_seq = c->h_seq_dev; ctl.seq = ++c->seq; ctl.npub = (kind == 4) ? 2 : 1; *seq_out = ctl.seq; }
   switch (kind) {
-  case 1: hipLaunchKernelGGL((norm_kernel<1>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, c->d_partials); break;
-  case 2: hipLaunchKernelGGL((norm_kernel<2>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, c->d_partials); break;
-  case 3: hipLaunchKernelGGL((norm_kernel<3>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, c->d_partials); break;
-  case 4: hipLaunchKernelGGL((norm_kernel<4>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, c->d_partials); break;
+  case 1: hipLaunchKernelGGL((norm_kernel<1>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, ctl); break;
+  case 2: hipLaunchKernelGGL((norm_kernel<2>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, ctl); break;
+  case 3: hipLaunchKernelGGL((norm_kernel<3>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, ctl); break;
+  case 4: hipLaunchKernelGGL((norm_kernel<4>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, ctl); break;
   default: PHIP_REQUIRE(0, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_reduce_local: kind %d", kind);
   }
   PHIP_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(PHIP_THREADS), 0, c->stream, grid, (kind == 4) ? 2 : 1, c->d_partials, d_out, (kind == 3) ? 1 : 0);
-  PHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int phip_vec_reduce_local(phip_ctx c, int kind, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *d_out)
+{
+  CHECK_CTX(c, "phip_vec_reduce_local"); CHECK_N(n, "phip_vec_reduce_local");
+  PHIP_REQUIRE(d_out, PHIP_ERR_ARG_NULL, "phip_vec_reduce_local: null output");
+  return reduce_launch(c, kind, n, d_x, nv, h_dy, d_out, 0, NULL);
+}
+
+/* launch + wait for the published result; r receives nres values */
+static int reduce_to_host(phip_ctx c, int kind, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, int nres, double *r)
+{
+  unsigned long long seq = 0;
+  int                rc = reduce_launch(c, kind, n, d_x, nv, h_dy, c->d_result, 1, &seq);
+  if (rc) return rc;
+  if ((rc = phip_wait_seq(c, seq))) return rc;
+  for (int i = 0; i < nres; i++) r[i] = c->h_slot[i];
   return 0;
 }
 
 extern "C" int phip_vec_dot(phip_ctx c, int32_t n, const double *d_x, const double *d_y, double *h_z)
 {
-  CHECK_CTX(c, "phip_vec_dot");
+  CHECK_CTX(c, "phip_vec_dot"); CHECK_N(n, "phip_vec_dot");
   PHIP_REQUIRE(h_z, PHIP_ERR_ARG_NULL, "phip_vec_dot: null result");
   const double *ys[1] = {d_y};
-  int           rc = phip_vec_reduce_local(c, 0, n, d_x, 1, ys, c->d_result);
-  if (rc) return rc;
-  return phip_read_scalars(c, c->d_result, 1, h_z);
+  return reduce_to_host(c, 0, n, d_x, 1, ys, 1, h_z);
 }
 
 extern "C" int phip_vec_mdot(phip_ctx c, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *h_z)
 {
-  CHECK_CTX(c, "phip_vec_mdot");
+  CHECK_CTX(c, "phip_vec_mdot"); CHECK_N(n, "phip_vec_mdot");
   PHIP_REQUIRE(h_z || !nv, PHIP_ERR_ARG_NULL, "phip_vec_mdot: null result");
+  PHIP_REQUIRE(nv >= 0 && nv <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_mdot: nv=%d (max %d)", nv, PHIP_MAX_MVEC);
   if (nv == 0) return 0;
-  int rc = phip_vec_reduce_local(c, 0, n, d_x, nv, h_dy, c->d_result);
-  if (rc) return rc;
-  return phip_read_scalars(c, c->d_result, nv, h_z);
+  return reduce_to_host(c, 0, n, d_x, nv, h_dy, nv, h_z);
 }
 
 extern "C" int phip_vec_norm(phip_ctx c, int32_t n, const double *d_x, int type, double *h_z)
 {
-  CHECK_CTX(c, "phip_vec_norm");
+  CHECK_CTX(c, "phip_vec_norm"); CHECK_N(n, "phip_vec_norm");
   PHIP_REQUIRE(h_z, PHIP_ERR_ARG_NULL, "phip_vec_norm: null result");
   int    rc;
   double r[2];
   switch (type) {
   case PHIP_NORM_2:
   case PHIP_NORM_FROBENIUS:
-    if ((rc = phip_vec_reduce_local(c, 1, n, d_x, 1, NULL, c->d_result))) return rc;
-    if ((rc = phip_read_scalars(c, c->d_result, 1, r))) return rc;
+    if ((rc = reduce_to_host(c, 1, n, d_x, 1, NULL, 1, r))) return rc;
     h_z[0] = sqrt(r[0]); /* bvec2.c:244-245 */
     return 0;
-  case PHIP_NORM_1:
-    if ((rc = phip_vec_reduce_local(c, 2, n, d_x, 1, NULL, c->d_result))) return rc;
-    return phip_read_scalars(c, c->d_result, 1, h_z);
-  case PHIP_NORM_INFINITY:
-    if ((rc = phip_vec_reduce_local(c, 3, n, d_x, 1, NULL, c->d_result))) return rc;
-    return phip_read_scalars(c, c->d_result, 1, h_z);
+  case PHIP_NORM_1: return reduce_to_host(c, 2, n, d_x, 1, NULL, 1, h_z);
+  case PHIP_NORM_INFINITY: return reduce_to_host(c, 3, n, d_x, 1, NULL, 1, h_z);
   case PHIP_NORM_1_AND_2:
-    if ((rc = phip_vec_reduce_local(c, 4, n, d_x, 1, NULL, c->d_result))) return rc;
-    if ((rc = phip_read_scalars(c, c->d_result, 2, r))) return rc;
+    if ((rc = reduce_to_host(c, 4, n, d_x, 1, NULL, 2, r))) return rc;
     h_z[0] = r[0]; h_z[1] = sqrt(r[1]);
     return 0;
   }

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--tpr", type=int, default=0)
     ap.add_argument("--vec", type=int, default=1)
+    ap.add_argument("--fmt", type=int, default=0)
     a = ap.parse_args()
     ctx = capi.Context(0)
     L = ctx.lib
@@ -32,6 +33,8 @@ def main():
     A = ctx.mat_create(m, m, ai, aj, aa)
     if a.tpr:
         ctx.check(L.phip_mat_set_threads_per_row(A, a.tpr))
+    if a.fmt:
+        ctx.check(L.phip_mat_set_format(A, a.fmt))
     print(json.dumps({k: (v if not isinstance(v, np.ndarray) else None) for k, v in ctx.mat_plan(A).items()}))
     x = G.random_vector(m)
     dx, dy, dz = ctx.to_device(x), ctx.to_device(np.zeros(m)), ctx.to_device(x[::-1].copy())

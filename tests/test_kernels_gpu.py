@@ -29,11 +29,25 @@ def relerr(a, b):
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-300)
 
 
-def gpu_mult(ctx, ai, aj, aa, n, x, cprow=None, y0=None, inplace=False, tpr=0):
+def mat_format(ctx, A):
+    import ctypes as C
+    f, nd, pad = C.c_int(), C.c_int32(), C.c_int64()
+    ctx.check(ctx.lib.phip_mat_format_info(A, C.byref(f), C.byref(nd), C.byref(pad)))
+    return f.value, nd.value, pad.value
+
+
+def gpu_mult(ctx, ai, aj, aa, n, x, cprow=None, y0=None, inplace=False, tpr=0, fmt=0):
+    """fmt 1: CSR row-block kernel, 2: SELL-dict kernel (returns None when the matrix is not eligible), 0: the library's choice."""
     m = len(ai) - 1
     A = ctx.mat_create(m, n, ai, aj, aa, cprow)
     if tpr:
+        fmt = 1  # lanes per row is a knob of the CSR row-block kernel
         ctx.check(ctx.lib.phip_mat_set_threads_per_row(A, tpr))
+    if fmt == 2 and ctx.lib.phip_mat_set_format(A, 2) != 0:
+        ctx.check(ctx.lib.phip_mat_destroy(A))
+        return None
+    if fmt == 1:
+        ctx.check(ctx.lib.phip_mat_set_format(A, 1))
     dx = ctx.to_device(x)
     dy = ctx.to_device(np.full(max(m, 1), 7.25))
     if y0 is None:
@@ -89,6 +103,59 @@ def test_spmv_stencils_and_rmat(ctx, orc):
         x = G.random_vector(n)
         y = gpu_mult(ctx, ai, aj, aa, n, x)
         assert relerr(y, orc.matmult(ai, aj, aa, x)) <= 1e-12
+
+
+def test_spmv_sell_dict_layout(ctx, orc, golden_dir):
+    """The SELL-dict layout (one-byte diagonal index) gives the reference's bits, like the one-lane-per-row CSR kernel; it is
+    chosen for the stencil matrices and refused for irregular ones."""
+    from petsc_amd import generators as G
+    rng = np.random.default_rng(3)
+    cases = [G.laplace3d_7pt(24), G.laplace3d_7pt(9, 31, 5, dirichlet_rows=False), G.box3d_27pt(17), G.convdiff3d_7pt(19, 13, 11),
+             G.laplace2d_5pt(57, 31), G.laplace2d_5pt(1, 700)]
+    for ai, aj, aa in cases:
+        n = len(ai) - 1
+        aa = aa * rng.uniform(0.5, 1.5, len(aa))
+        x = G.random_vector(n)
+        yo = orc.matmult(ai, aj, aa, x)
+        A = ctx.mat_create(n, n, ai, aj, aa)
+        f, nd, pad = mat_format(ctx, A)
+        assert f == 2 and nd <= 27 and pad >= len(aj)
+        ctx.check(ctx.lib.phip_mat_destroy(A))
+        np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, fmt=2), yo)
+        np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, tpr=1), yo)
+        y0 = rng.standard_normal(n)
+        zo = orc.matmultadd(ai, aj, aa, x, y0)
+        np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, y0=y0, fmt=2), zo)
+        np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, y0=y0, inplace=True, fmt=2), zo)
+    # rectangular, odd row count, empty rows in the middle, x containing Inf where no entry points (padding must not touch it)
+    ai = np.array([0, 2, 2, 3, 5, 5], np.int32); aj = np.array([0, 1, 2, 3, 4], np.int32); aa = np.arange(1.0, 6.0)
+    x = np.array([1.0, 2.0, 3.0, 4.0, 5.0, np.inf, np.nan])
+    np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, 7, x, fmt=2), orc.matmult(ai, aj, aa, x))
+    # irregular matrices stay on the CSR row-block kernel
+    ai, aj, aa = G.rmat(12)
+    assert gpu_mult(ctx, ai, aj, aa, len(ai) - 1, np.ones(len(ai) - 1), fmt=2) is None
+    for name in ("arco1", "medium", "small", "tiny"):
+        g = np.load(os.path.join(golden_dir, "mat_%s.npz" % name), allow_pickle=False)
+        for fmt in (1, 2):
+            y = gpu_mult(ctx, g["i"], g["j"], g["a"], int(g["N"]), g["x"], fmt=fmt)
+            if y is not None:
+                assert relerr(y, g["y"]) <= 1e-12
+    # values-only update keeps both layouts in step
+    ai, aj, aa = G.laplace3d_7pt(10)
+    n = len(ai) - 1
+    A = ctx.mat_create(n, n, ai, aj, aa)
+    aa2 = aa * 1.75 + 0.125
+    ctx.check(ctx.lib.phip_mat_update_values(A, aa2.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double))))
+    x = G.random_vector(n); dx = ctx.to_device(x); dy = ctx.to_device(np.zeros(n))
+    for fmt in (2, 1):
+        ctx.check(ctx.lib.phip_mat_set_format(A, fmt))
+        ctx.check(ctx.lib.phip_mat_mult(A, dx, dy))
+        got = ctx.to_host(dy, n)
+        if fmt == 2:
+            np.testing.assert_array_equal(got, orc.matmult(ai, aj, aa2, x))
+        else:
+            assert relerr(got, orc.matmult(ai, aj, aa2, x)) <= 1e-12
+    ctx.free(dx); ctx.free(dy); ctx.check(ctx.lib.phip_mat_destroy(A))
 
 
 def test_spmv_long_rows_and_edges(ctx, orc):
