@@ -10,7 +10,7 @@
  * Conventions
  *   - PetscInt = int32_t, PetscScalar = PetscReal = double.
  *   - Return value: 0 on success, otherwise a PetscErrorCode value (include/petscerror.h:24-68):
- *       PHIP_ERR_MEM 55, PHIP_ERR_SUP 56, PHIP_ERR_ARG_SIZ 60, PHIP_ERR_ARG_OUTOFRANGE 63,
+ *       PHIP_ERR_MEM 55, PHIP_ERR_SUP 56, PHIP_ERR_ARG_SIZ 60, PHIP_ERR_ARG_WRONG 62, PHIP_ERR_ARG_OUTOFRANGE 63,
  *       PHIP_ERR_ARG_WRONGSTATE 73, PHIP_ERR_LIB 76 (any HIP / RCCL failure), PHIP_ERR_ARG_NULL 85.
  *     phip_last_error() returns the text of the last failure on the calling thread.
  *   - "d_" pointers are device pointers obtained from phip_malloc (or any hipMalloc'd memory);
@@ -36,6 +36,7 @@ extern "C" {
 #define PHIP_ERR_MEM            55
 #define PHIP_ERR_SUP            56
 #define PHIP_ERR_ARG_SIZ        60
+#define PHIP_ERR_ARG_WRONG      62
 #define PHIP_ERR_ARG_OUTOFRANGE 63
 #define PHIP_ERR_ARG_WRONGSTATE 73
 #define PHIP_ERR_LIB            76
@@ -143,6 +144,25 @@ int phip_jacobi_setup(phip_ctx ctx, int32_t n, double *d_diag, int useabs, int s
  * kind: 0 dot(x,y[0]) / mdot(x,y[0..nv-1]);  1 sum x_i^2 (nv=1);  2 sum |x_i| ;  3 max |x_i| (NaN propagates);  4 {sum|x|, sum x^2} */
 int phip_vec_reduce_local(phip_ctx ctx, int kind, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *d_out);
 int phip_read_scalars(phip_ctx ctx, const double *d_src, int32_t n, double *h_dst);
+
+/* ---- by-product reductions --------------------------------------------------------------------------
+ * On this hardware a reduction fused into a kernel that streams the operands anyway costs a few microseconds, while a reduction of
+ * its own costs a pass over HBM plus a launch and a host round trip.  The calls below produce, next to their normal result, the
+ * sums the Krylov callers ask for right afterwards (cg.c:206-207 MatMult then VecTDot(P,W); cg.c:225-229,269 PCApply then VecNorm(Z)
+ * and VecTDot(Z,R)), and leave them in a slot of a small ring named by a ticket.  The glue keeps the ticket with the output vector,
+ * keyed on the PetscObjectState of the operands (the mechanism of VecNorm's own cache, rvector.c:237-247), and serves a matching
+ * VecDot / VecNorm from it: phip_ticket_wait (one rank; publish != 0 made the kernel write the pinned slot the host spins on), or
+ * phip_ticket_values + phip_comm_allreduce + phip_read_scalars (several ranks).  A ticket expires after 63 newer ones.
+ * Values are local sums, bitwise deterministic for a given length and grid. */
+typedef struct { int32_t slot, nvals; uint64_t seq; } phip_ticket;
+/* w = x .* y (VecPointwiseMult_Seq bvec2.c:84-110, w aliasing neither x nor y); values {sum w^2, sum w x, sum w y} */
+int phip_vec_pointwise_mult_reduce(phip_ctx ctx, int32_t n, double *d_w, const double *d_x, const double *d_y, int publish, phip_ticket *t);
+/* y = A x (phip_mat_mult); value {sum_i v_i y_i}, d_v has m entries (the caller passes x for a square matrix) */
+int phip_mat_mult_dot(phip_mat A, const double *d_x, double *d_y, const double *d_v, int publish, phip_ticket *t);
+/* y += A x in place (phip_mat_multadd with z == y, mpiaij.c:996); adds sum_i v_i (y_new_i - y_old_i) to the value of the live ticket t */
+int phip_mat_multadd_dot(phip_mat A, const double *d_x, double *d_y, const double *d_v, const phip_ticket *t);
+int phip_ticket_values(phip_ctx ctx, const phip_ticket *t, double **d_vals);
+int phip_ticket_wait(phip_ctx ctx, const phip_ticket *t, double *h_vals);
 
 /* ---- communicator: one rank per GPU, RCCL over xGMI ---------------------------------------------
  * Replaces MPI_Allreduce in the MPI Vec types and the MPI persistent send/recv of VecScatterBegin/End

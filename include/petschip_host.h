@@ -70,6 +70,8 @@ PetscErrorCode PetscHipInitialize(int device, const char *backend, const void *i
  * device = -1 gives a planning-only context: assembly, MatSetUpMultiply and the scatter plan run, numerical calls fail. */
 PetscErrorCode PetscHipInitializeWithCallbacks(int device, int nranks, int rank, phip_allgather_fn allgather, phip_alltoallv_i32_fn alltoallv, void *user, PetscComm *world);
 PetscErrorCode PetscHipFinalize(PetscComm *world);
+/* by-product reductions (include/petschip.h "by-product reductions"): on by default; PETSC_FALSE makes every VecDot/VecNorm a kernel of its own */
+PetscErrorCode PetscHipSetByProducts(PetscComm comm, PetscBool flg);
 PetscErrorCode PetscCommGetSelf(PetscComm world, PetscComm *self);     /* PETSC_COMM_SELF */
 PetscErrorCode PetscCommRankSize(PetscComm comm, int *rank, int *size); /* MPI_Comm_rank / MPI_Comm_size */
 PetscErrorCode PetscCommGetContext(PetscComm comm, phip_ctx *ctx);

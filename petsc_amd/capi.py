@@ -59,6 +59,11 @@ SIGNATURES = [
     ("phip_vec_set", C.c_int, [_vp, C.c_int32, _vp, C.c_double]),
     ("phip_vec_swap", C.c_int, [_vp, C.c_int32, _vp, _vp]),
     ("phip_vec_reciprocal", C.c_int, [_vp, C.c_int32, _vp]),
+    ("phip_vec_pointwise_mult_reduce", C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, C.c_int, _vp]),
+    ("phip_mat_mult_dot", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
+    ("phip_mat_multadd_dot", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    ("phip_ticket_values", C.c_int, [_vp, _vp, C.POINTER(_vp)]),
+    ("phip_ticket_wait", C.c_int, [_vp, _vp, _pD]),
     ("phip_jacobi_setup", C.c_int, [_vp, C.c_int32, _vp, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     ("phip_vec_reduce_local", C.c_int, [_vp, C.c_int, C.c_int32, _vp, C.c_int32, C.POINTER(_vp), _vp]),
     ("phip_read_scalars", C.c_int, [_vp, _vp, C.c_int32, _pD]),
@@ -76,6 +81,10 @@ SIGNATURES = [
     ("phip_halo_begin", C.c_int, [_vp, _vp, _vp]),
     ("phip_halo_end", C.c_int, [_vp]),
 ]
+
+
+class Ticket(C.Structure):
+    _fields_ = [("slot", C.c_int32), ("nvals", C.c_int32), ("seq", C.c_uint64)]
 
 
 class PhipError(RuntimeError):

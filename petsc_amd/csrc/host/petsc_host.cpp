@@ -56,7 +56,14 @@ struct _p_PetscComm {
   bool      is_world;
   double   *d_red; /* device scratch for distributed reductions: PHIP_MAX_MVEC doubles */
   _p_PetscComm *self;
+  /* by-product reductions (include/petschip.h): kind 1 = VecPointwiseMult, kind 2 = MatMult.  A kind switches itself off after 8
+     productions in a row that nobody consumed (GMRES never asks for them) and on again when a request comes that it would have served */
+  bool      bp_allowed;
+  bool      bp_on[3];
+  int       bp_streak[3];
+  _p_PetscComm *root; /* the world communicator that owns the switches (self shares them) */
 };
+#define BP(c) ((c)->root)
 
 extern "C" PetscErrorCode PetscHipInitialize(int device, const char *backend, const void *id128, int nranks, int rank, PetscComm *world)
 {
@@ -72,7 +79,18 @@ extern "C" PetscErrorCode PetscHipInitialize(int device, const char *backend, co
   s->ctx = w->ctx; s->rank = 0; s->size = 1; s->is_world = false; s->d_red = w->d_red;
   CHKPHIP(phip_comm_create(w->ctx, "self", NULL, 1, 0, &s->comm));
   s->self = s; w->self = s;
+  w->root = w; s->root = w;
+  w->bp_allowed = true; w->bp_on[1] = w->bp_on[2] = true;
   *world = w;
+  return 0;
+}
+
+extern "C" PetscErrorCode PetscHipSetByProducts(PetscComm comm, PetscBool flg)
+{
+  if (!comm) SETERRQ(PETSC_ERR_ARG_NULL, "PetscHipSetByProducts: null communicator");
+  BP(comm)->bp_allowed = flg != 0;
+  BP(comm)->bp_on[1] = BP(comm)->bp_on[2] = flg != 0;
+  BP(comm)->bp_streak[1] = BP(comm)->bp_streak[2] = 0;
   return 0;
 }
 
@@ -92,6 +110,8 @@ extern "C" PetscErrorCode PetscHipInitializeWithCallbacks(int device, int nranks
   s->ctx = w->ctx; s->rank = 0; s->size = 1; s->is_world = false; s->d_red = w->d_red;
   CHKPHIP(phip_comm_create(w->ctx, "self", NULL, 1, 0, &s->comm));
   s->self = s; w->self = s;
+  w->root = w; s->root = w;
+  w->bp_allowed = false; /* set-up-only communicator: no device traffic, no by-products */
   *world = w;
   return 0;
 }
@@ -190,7 +210,11 @@ struct _VecOps { /* the slots of include/petsc/private/vecimpl.h:20-96 that this
   PetscErrorCode (*destroy)(Vec);
 };
 
+#include <atomic>
+static std::atomic<uint64_t> g_next_object_id{1};
+
 struct _p_Vec {
+  uint64_t    id = g_next_object_id++;
   PetscComm   comm;
   std::string type;
   PetscInt    n, N;
@@ -202,6 +226,17 @@ struct _p_Vec {
   uint64_t    state;      /* PetscObjectState: bumped on every write (rvector.c:1865 et al.) */
   std::vector<PetscInt> stash_i; std::vector<double> stash_v; std::vector<int> stash_mode;
   _VecOps     ops;
+  /* by-products of the operation that last wrote this vector: kind 1 (w = x .* y): {sum w^2, sum w x, sum w y}, partners x, y;
+     kind 2 (y = A x): {sum x y}, partner x.  Valid while the object states still match (cf. the norm cache, rvector.c:237-247). */
+  struct {
+    int         kind;
+    bool        live, consumed, have_host;
+    phip_ticket ticket;
+    uint64_t    self_state;
+    uint64_t    partner[2]; /* object ids (not pointers: a destroyed partner's address may be reused) */
+    uint64_t    partner_state[2];
+    double      host[3];
+  } bp;
 };
 
 static std::map<std::string, PetscErrorCode (*)(Vec)> &VecList()
@@ -224,6 +259,7 @@ extern "C" PetscErrorCode VecCreate(PetscComm comm, Vec *v)
   Vec x = new _p_Vec();
   x->comm = comm; x->n = PETSC_DECIDE; x->N = PETSC_DECIDE; x->setup = false; x->d = NULL; x->host_out = 0; x->state = 0;
   memset(&x->ops, 0, sizeof(x->ops));
+  memset(&x->bp, 0, sizeof(x->bp));
   *v = x;
   return 0;
 }
@@ -240,6 +276,76 @@ extern "C" PetscErrorCode VecSetSizes(Vec v, PetscInt n, PetscInt N)
 #define VCTX(v) ((v)->comm->ctx)
 #define VecCheckReady(v, name) do { if (!(v)) SETERRQ(PETSC_ERR_ARG_NULL, name ": null vector"); if (!(v)->setup) SETERRQ(PETSC_ERR_ARG_TYPENOTSET, name ": vector type/sizes not set"); if ((v)->host_out == 2) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, name ": VecGetArray() is outstanding; call VecRestoreArray() first"); } while (0)
 #define VecCheckSame(x, y, name) do { if ((x)->n != (y)->n || (x)->N != (y)->N) SETERRQ(PETSC_ERR_ARG_INCOMP, name ": incompatible vector lengths (local %d vs %d, global %d vs %d)", (x)->n, (y)->n, (x)->N, (y)->N); } while (0)
+
+/* ---- by-product bookkeeping ---- */
+/* called by a producing op before it overwrites w: w's previous by-products, if nobody asked for them, count against the kind */
+static bool bp_want(Vec w, int kind)
+{
+  PetscComm r = BP(w->comm);
+  if (!r->bp_allowed) return false;
+  if (w->bp.kind == kind && w->bp.live) {
+    if (w->bp.consumed) r->bp_streak[kind] = 0;
+    else if (++r->bp_streak[kind] >= 8) r->bp_on[kind] = false;
+  }
+  return r->bp_on[kind];
+}
+static void bp_record(Vec w, int kind, bool live, const phip_ticket *t, Vec p0, Vec p1)
+{
+  w->bp.kind = kind; w->bp.live = live; w->bp.consumed = false; w->bp.have_host = false;
+  if (t) w->bp.ticket = *t;
+  w->bp.self_state = w->state + 1; /* the interface wrapper bumps the state once after the op */
+  w->bp.partner[0] = p0 ? p0->id : 0; w->bp.partner_state[0] = p0 ? p0->state : 0;
+  w->bp.partner[1] = p1 ? p1->id : 0; w->bp.partner_state[1] = p1 ? p1->state : 0;
+}
+/* bring the (global) values of w's by-products to the host: spin on the pinned slot (one rank) or all-reduce the device slot */
+static bool bp_fetch(Vec w)
+{
+  if (w->bp.have_host) return true;
+  const int n = w->bp.ticket.nvals;
+  if (w->comm->size == 1) {
+    if (phip_ticket_wait(VCTX(w), &w->bp.ticket, w->bp.host)) { w->bp.live = false; return false; }
+  } else {
+    double *d;
+    if (phip_ticket_values(VCTX(w), &w->bp.ticket, &d)) { w->bp.live = false; return false; } /* expired identically on every rank */
+    if (phip_comm_allreduce(w->comm->comm, d, n, 0)) { w->bp.live = false; return false; }
+    if (phip_read_scalars(VCTX(w), d, n, w->bp.host)) { w->bp.live = false; return false; }
+  }
+  w->bp.have_host = true; w->bp.consumed = true;
+  return true;
+}
+/* is x . y among the by-products of x or of y?  idx of the value in host[]: kind 1: 1 + partner index, kind 2: 0 */
+static bool bp_try_dot(Vec x, Vec y, PetscScalar *val)
+{
+  Vec pair[2][2] = {{x, y}, {y, x}};
+  for (int q = 0; q < 2; q++) {
+    Vec w = pair[q][0], o = pair[q][1];
+    if (!w->bp.kind || w->bp.self_state != w->state) continue;
+    for (int i = 0; i < 2; i++) {
+      if (w->bp.partner[i] != o->id || w->bp.partner_state[i] != o->state) continue;
+      if (!w->bp.live) { /* it would have been served: switch the kind back on */
+        PetscComm r = BP(w->comm);
+        if (r->bp_allowed) { r->bp_on[w->bp.kind] = true; r->bp_streak[w->bp.kind] = 0; }
+        return false;
+      }
+      if (!bp_fetch(w)) return false;
+      *val = w->bp.host[w->bp.kind == 1 ? 1 + i : 0];
+      return true;
+    }
+  }
+  return false;
+}
+static bool bp_try_norm2(Vec w, PetscReal *val)
+{
+  if (w->bp.kind != 1 || w->bp.self_state != w->state) return false;
+  if (!w->bp.live) {
+    PetscComm r = BP(w->comm);
+    if (r->bp_allowed) { r->bp_on[1] = true; r->bp_streak[1] = 0; }
+    return false;
+  }
+  if (!bp_fetch(w)) return false;
+  *val = sqrt(w->bp.host[0]);
+  return true;
+}
 
 /* ---- HIP implementations of the ops: Seq versions, then the MPI reductions ---- */
 static PetscErrorCode VecDuplicate_HIP(Vec v, Vec *w);
@@ -320,7 +426,21 @@ static PetscErrorCode VecMAXPY_HIP(Vec y, PetscInt nv, const PetscScalar *al, Ve
 static PetscErrorCode VecAYPX_HIP(Vec y, PetscScalar a, Vec x) { CHKPHIP(phip_vec_aypx(VCTX(y), y->n, y->d, a, x->d)); return 0; }
 static PetscErrorCode VecWAXPY_HIP(Vec w, PetscScalar a, Vec x, Vec y) { CHKPHIP(phip_vec_waxpy(VCTX(w), w->n, w->d, a, x->d, y->d)); return 0; }
 static PetscErrorCode VecAXPBYPCZ_HIP(Vec z, PetscScalar a, PetscScalar b, PetscScalar g, Vec x, Vec y) { CHKPHIP(phip_vec_axpbypcz(VCTX(z), z->n, z->d, a, b, g, x->d, y->d)); return 0; }
-static PetscErrorCode VecPointwiseMult_HIP(Vec w, Vec x, Vec y) { CHKPHIP(phip_vec_pointwise_mult(VCTX(w), w->n, w->d, x->d, y->d)); return 0; }
+static PetscErrorCode VecPointwiseMult_HIP(Vec w, Vec x, Vec y)
+{
+  if (w != x && w != y && x != y) {
+    const bool want = bp_want(w, 1);
+    if (want) {
+      phip_ticket t;
+      CHKPHIP(phip_vec_pointwise_mult_reduce(VCTX(w), w->n, w->d, x->d, y->d, w->comm->size == 1, &t));
+      bp_record(w, 1, true, &t, x, y);
+      return 0;
+    }
+    bp_record(w, 1, false, NULL, x, y);
+  }
+  CHKPHIP(phip_vec_pointwise_mult(VCTX(w), w->n, w->d, x->d, y->d));
+  return 0;
+}
 static PetscErrorCode VecPointwiseDivide_HIP(Vec w, Vec x, Vec y) { CHKPHIP(phip_vec_pointwise_divide(VCTX(w), w->n, w->d, x->d, y->d)); return 0; }
 static PetscErrorCode VecReciprocal_HIP(Vec x) { CHKPHIP(phip_vec_reciprocal(VCTX(x), x->n, x->d)); return 0; }
 
@@ -393,6 +513,7 @@ static PetscErrorCode VecDuplicate_HIP(Vec v, Vec *w)
   Vec x = new _p_Vec();
   x->comm = v->comm; x->type = v->type; x->n = v->n; x->N = v->N; x->range = v->range; x->setup = true; x->host_out = 0; x->state = 0;
   x->ops = v->ops; x->d = NULL;
+  memset(&x->bp, 0, sizeof(x->bp));
   CHKPHIP(phip_malloc(VCTX(v), sizeof(double) * (size_t)v->n, (void **)&x->d));
   if (ctx_has_device(VCTX(v))) CHKPHIP(phip_vec_set(VCTX(v), x->n, x->d, 0.0));
   *w = x;
@@ -610,12 +731,14 @@ extern "C" PetscErrorCode VecDot(Vec x, Vec y, PetscScalar *val)
 {
   VecCheckReady(x, "VecDot"); VecCheckReady(y, "VecDot"); VecCheckSame(x, y, "VecDot");
   if (!val) SETERRQ(PETSC_ERR_ARG_NULL, "VecDot: null result");
+  if (bp_try_dot(x, y, val)) return 0;
   return (*x->ops.dot)(x, y, val);
 }
 extern "C" PetscErrorCode VecTDot(Vec x, Vec y, PetscScalar *val)
 {
   VecCheckReady(x, "VecTDot"); VecCheckReady(y, "VecTDot"); VecCheckSame(x, y, "VecTDot");
   if (!val) SETERRQ(PETSC_ERR_ARG_NULL, "VecTDot: null result");
+  if (bp_try_dot(x, y, val)) return 0; /* real scalars: TDot == Dot */
   return (*x->ops.tdot)(x, y, val);
 }
 extern "C" PetscErrorCode VecMDot(Vec x, PetscInt nv, const Vec y[], PetscScalar val[])
@@ -630,6 +753,7 @@ extern "C" PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val)
 {
   VecCheckReady(x, "VecNorm");
   if (!val) SETERRQ(PETSC_ERR_ARG_NULL, "VecNorm: null result");
+  if ((type == NORM_2 || type == NORM_FROBENIUS) && bp_try_norm2(x, val)) return 0;
   return (*x->ops.norm)(x, type, val);
 }
 /* VecNormalize rvector.c:328-347: skip scaling when the norm is 0 or 1; scale by tmp = 1.0/norm */
@@ -891,7 +1015,20 @@ static PetscErrorCode MatAssemblyEnd_SeqAIJHIP(Mat A, MatAssemblyType type)
   A->A.assembly_end();
   return A->A.upload(MCTX(A)); /* precedent MatAssemblyEnd_SeqAIJCUSP aijcusp.cu:451-462: CPU assemble, then copy to the GPU */
 }
-static PetscErrorCode MatMult_SeqAIJHIP(Mat A, Vec x, Vec y) { CHKPHIP(phip_mat_mult(A->A.dev, x->d, y->d)); return 0; }
+static PetscErrorCode MatMult_SeqAIJHIP(Mat A, Vec x, Vec y)
+{
+  if (A->m == A->n) { /* by-product sum x_i y_i: KSPSolve_CG asks for VecTDot(P,W) right after MatMult(A,P,W), cg.c:206-207 */
+    if (bp_want(y, 2)) {
+      phip_ticket t;
+      CHKPHIP(phip_mat_mult_dot(A->A.dev, x->d, y->d, x->d, 1, &t));
+      bp_record(y, 2, true, &t, x, NULL);
+      return 0;
+    }
+    bp_record(y, 2, false, NULL, x, NULL);
+  }
+  CHKPHIP(phip_mat_mult(A->A.dev, x->d, y->d));
+  return 0;
+}
 static PetscErrorCode MatMultAdd_SeqAIJHIP(Mat A, Vec x, Vec y, Vec z) { CHKPHIP(phip_mat_multadd(A->A.dev, x->d, y->d, z->d)); return 0; }
 static PetscErrorCode MatGetDiagonal_SeqAIJHIP(Mat A, Vec v) { CHKPHIP(phip_mat_getdiagonal(A->A.dev, v->d)); return 0; }
 static PetscErrorCode MatZeroEntries_AIJHIP(Mat A)
@@ -1091,10 +1228,16 @@ static PetscErrorCode MatAssemblyEnd_MPIAIJHIP(Mat A, MatAssemblyType type)
 /* MatMult_MPIAIJ mpiaij.c:984-998: ScatterBegin; A*x; ScatterEnd; y += B*lvec -- the exchange overlaps the diagonal block */
 static PetscErrorCode MatMult_MPIAIJHIP(Mat A, Vec x, Vec y)
 {
+  const bool square = A->m == A->n;
+  const bool want = square && bp_want(y, 2);
+  phip_ticket t;
   CHKPHIP(phip_halo_begin(A->halo, x->d, A->lvec));
-  CHKPHIP(phip_mat_mult(A->A.dev, x->d, y->d));
+  if (want) CHKPHIP(phip_mat_mult_dot(A->A.dev, x->d, y->d, x->d, 0, &t)); /* local sum x_i (A_d x)_i ... */
+  else CHKPHIP(phip_mat_mult(A->A.dev, x->d, y->d));
   CHKPHIP(phip_halo_end(A->halo));
-  CHKPHIP(phip_mat_multadd(A->B.dev, A->lvec, y->d, y->d));
+  if (want) CHKPHIP(phip_mat_multadd_dot(A->B.dev, A->lvec, y->d, x->d, &t)); /* ... + sum x_i (B lvec)_i */
+  else CHKPHIP(phip_mat_multadd(A->B.dev, A->lvec, y->d, y->d));
+  if (square) bp_record(y, 2, want, want ? &t : NULL, x, NULL);
   return 0;
 }
 /* MatMultAdd_MPIAIJ mpiaij.c:1014-1025 */

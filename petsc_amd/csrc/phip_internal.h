@@ -9,6 +9,10 @@
 #define PHIP_RED_BLOCKS 1024 /* grid of every reduction kernel: fixed => deterministic summation tree */
 #define PHIP_THREADS 256
 
+#define PHIP_RING 64
+#define PHIP_RING_VALS 8
+struct phip_ring_slot { unsigned long long seq; double vals[PHIP_RING_VALS - 1]; }; /* 64 bytes */
+
 struct phip_ctx_s {
   int          device;
   int          cu_count;
@@ -22,6 +26,10 @@ struct phip_ctx_s {
   double      *h_slot_dev;  // device address of h_slot
   unsigned long long *h_seq, *h_seq_dev; // sequence word the host spins on
   unsigned long long  seq;  // last sequence number issued
+  /* by-product reductions (phip_ticket): ring of result slots, device side and pinned host side */
+  double      *d_ring;      // [PHIP_RING][PHIP_RING_VALS]
+  struct phip_ring_slot *h_ring, *h_ring_dev; // [PHIP_RING]
+  unsigned long long ring_seq; // tickets issued so far
   int         *d_flag;      // small int scratch (jacobi zero flag)
   int         *h_flag;      // pinned
   int          prof_on;     // phip_profile_enable: hipEvent pair around every SpMV launch
@@ -31,6 +39,12 @@ struct phip_ctx_s {
 /* profiling records (phip_runtime.hip): kind 0 = MatMult launches, 1 = MatMultAdd launches */
 /* wait until the device has published sequence number seq into c->h_seq (spin, with a periodic stream health check) */
 int phip_wait_seq(phip_ctx c, unsigned long long seq);
+
+/* by-product tickets (phip_runtime.hip): fill a RedCtl for a kernel that leaves nvals results in a fresh ring slot */
+struct RedCtl;
+int phip_ticket_open(phip_ctx c, int nvals, int publish, phip_ticket *t, struct RedCtl *ctl);
+/* ... or adds one more contribution to the live ticket t */
+int phip_ticket_accumulate(phip_ctx c, const phip_ticket *t, struct RedCtl *ctl);
 
 int phip_prof_open(phip_ctx c, int kind, hipEvent_t *start, hipEvent_t *stop);
 

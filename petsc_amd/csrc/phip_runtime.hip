@@ -1,5 +1,6 @@
 // Context, memory and error plumbing of libpetschip (see include/petschip.h).
 #include "phip_internal.h"
+#include "phip_reduce.h"
 #include <stdarg.h>
 #include <stdlib.h>
 #include <vector>
@@ -57,6 +58,12 @@ extern "C" int phip_init(int device, phip_ctx *out)
   PHIP_CHECK_HIP(hipHostGetDevicePointer((void **)&c->h_slot_dev, c->h_slot, 0));
   PHIP_CHECK_HIP(hipHostGetDevicePointer((void **)&c->h_seq_dev, c->h_seq, 0));
   *c->h_seq = 0; c->seq = 0;
+  PHIP_CHECK_HIP(hipMalloc((void **)&c->d_ring, sizeof(double) * PHIP_RING * PHIP_RING_VALS));
+  PHIP_CHECK_HIP(hipMemsetAsync(c->d_ring, 0, sizeof(double) * PHIP_RING * PHIP_RING_VALS, c->stream));
+  PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_ring, sizeof(phip_ring_slot) * PHIP_RING, hipHostMallocMapped | hipHostMallocCoherent));
+  PHIP_CHECK_HIP(hipHostGetDevicePointer((void **)&c->h_ring_dev, c->h_ring, 0));
+  memset(c->h_ring, 0, sizeof(phip_ring_slot) * PHIP_RING);
+  c->ring_seq = 0;
   PHIP_CHECK_HIP(hipMalloc((void **)&c->d_flag, sizeof(int) * 16));
   PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_flag, sizeof(int) * 16, hipHostMallocDefault));
   PHIP_CHECK_HIP(hipMemsetAsync(c->d_flag, 0, sizeof(int) * 16, c->stream));
@@ -72,7 +79,7 @@ extern "C" int phip_finalize(phip_ctx c)
   PHIP_CHECK_HIP(hipSetDevice(c->device));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->comm_stream));
-  hipFree(c->d_ticket); hipHostFree(c->h_slot); hipHostFree(c->h_seq);
+  hipFree(c->d_ticket); hipHostFree(c->h_slot); hipHostFree(c->h_seq); hipFree(c->d_ring); hipHostFree(c->h_ring);
   hipFree(c->d_partials); hipFree(c->d_result); hipHostFree(c->h_result); hipFree(c->d_flag); hipHostFree(c->h_flag);
   if (c->prof) {
     for (int k = 0; k < 2; k++) for (int w = 0; w < 2; w++) for (hipEvent_t e : c->prof->ev[k][w]) hipEventDestroy(e);
@@ -291,5 +298,64 @@ extern "C" int phip_profile_read(phip_ctx c, int kind, int32_t *count, double *s
   if (sum_ms) *sum_ms = s;
   if (min_ms) *min_ms = lo;
   if (max_ms) *max_ms = hi;
+  return 0;
+}
+
+/* ---- by-product tickets -------------------------------------------------------------------------- */
+int phip_ticket_open(phip_ctx c, int nvals, int publish, phip_ticket *t, RedCtl *ctl)
+{
+  PHIP_REQUIRE(t && ctl && nvals >= 1 && nvals < PHIP_RING_VALS, PHIP_ERR_ARG_OUTOFRANGE, "phip_ticket_open: nvals %d", nvals);
+  const unsigned long long seq = ++c->ring_seq;
+  const int                slot = (int)(seq % PHIP_RING);
+  t->slot = slot; t->nvals = nvals; t->seq = seq;
+  ctl->partial = c->d_partials; ctl->ticket = c->d_ticket; ctl->d_out = c->d_ring + (size_t)slot * PHIP_RING_VALS;
+  ctl->kofs = 0; ctl->accumulate = 0; ctl->npub = 0; ctl->h_slot = NULL; ctl->h_seq = NULL; ctl->seq = 0;
+  if (publish) { ctl->h_slot = c->h_ring_dev[slot].vals; ctl->h_seq = &c->h_ring_dev[slot].seq; ctl->seq = seq; ctl->npub = nvals; }
+  return 0;
+}
+
+static int ticket_live(phip_ctx c, const phip_ticket *t)
+{
+  return t && t->seq && t->seq <= c->ring_seq && c->ring_seq - t->seq < PHIP_RING && t->slot == (int)(t->seq % PHIP_RING) && t->nvals >= 1 && t->nvals < PHIP_RING_VALS;
+}
+
+int phip_ticket_accumulate(phip_ctx c, const phip_ticket *t, RedCtl *ctl)
+{
+  PHIP_REQUIRE(ticket_live(c, t), PHIP_ERR_ARG_WRONGSTATE, "phip_ticket_accumulate: the ticket has expired");
+  ctl->partial = c->d_partials; ctl->ticket = c->d_ticket; ctl->d_out = c->d_ring + (size_t)t->slot * PHIP_RING_VALS;
+  ctl->kofs = 0; ctl->accumulate = 1; ctl->npub = 0; ctl->h_slot = NULL; ctl->h_seq = NULL; ctl->seq = 0;
+  return 0;
+}
+
+extern "C" int phip_ticket_values(phip_ctx c, const phip_ticket *t, double **d_vals)
+{
+  PHIP_REQUIRE(c && d_vals, PHIP_ERR_ARG_NULL, "phip_ticket_values: null argument");
+  PHIP_NEED_DEVICE(c, "phip_ticket_values");
+  PHIP_REQUIRE(ticket_live(c, t), PHIP_ERR_ARG_WRONGSTATE, "phip_ticket_values: the ticket has expired");
+  *d_vals = c->d_ring + (size_t)t->slot * PHIP_RING_VALS;
+  return 0;
+}
+
+extern "C" int phip_ticket_wait(phip_ctx c, const phip_ticket *t, double *h_vals)
+{
+  PHIP_REQUIRE(c && h_vals, PHIP_ERR_ARG_NULL, "phip_ticket_wait: null argument");
+  PHIP_NEED_DEVICE(c, "phip_ticket_wait");
+  PHIP_REQUIRE(ticket_live(c, t), PHIP_ERR_ARG_WRONGSTATE, "phip_ticket_wait: the ticket has expired");
+  volatile unsigned long long *p = &c->h_ring[t->slot].seq;
+  for (unsigned long spin = 1;; spin++) {
+    if (*p == t->seq) break;
+    if ((spin & 0x3FFF) == 0) {
+      hipError_t e = hipStreamQuery(c->stream);
+      if (e == hipSuccess) {
+        if (*p == t->seq) break;
+        phip_set_error("phip_ticket_wait: the stream drained but ticket %llu was never published (was it opened without publish?)", t->seq);
+        return PHIP_ERR_ARG_WRONGSTATE;
+      }
+      if (e != hipErrorNotReady) { phip_set_error("phip_ticket_wait: %s", hipGetErrorString(e)); return PHIP_ERR_LIB; }
+    }
+    __builtin_ia32_pause();
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  for (int i = 0; i < t->nvals; i++) h_vals[i] = c->h_ring[t->slot].vals[i];
   return 0;
 }

@@ -27,6 +27,7 @@
 // separately rounded multiply and add: again the arithmetic of PetscSparseDensePlusDot bit for bit.  The CSR arrays stay on the
 // device for MatGetDiagonal and as the source of truth.
 #include "phip_internal.h"
+#include "phip_reduce.h"
 #include <stdlib.h>
 #include <vector>
 
@@ -65,10 +66,34 @@ struct phip_mat_s {
   std::vector<int64_t> *h_sptr;
 };
 
-template <int TPR>
+/* Matrix entries are read once per launch.  When the matrix is much larger than the 256 MiB Infinity Cache, non-temporal loads keep
+   the stream from displacing x in L2 / Infinity Cache (27-point 160^3: 221 -> 205 us); a matrix that fits the cache is better left
+   cacheable, because the next launch finds it there (7-point 128^3: 26.8 us cacheable, 32.0 us non-temporal). */
+#define PHIP_NT_MATRIX_BYTES (192ll << 20)
+template <bool NT>
+__device__ __forceinline__ double2 ld_stream(const double2 *p)
+{
+  if (NT) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
+    return make_double2(v.x, v.y);
+  }
+  return *p;
+}
+template <bool NT>
+__device__ __forceinline__ uchar2 ld_stream(const uchar2 *p)
+{
+  if (NT) {
+    const unsigned short v = __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(p));
+    return make_uchar2((unsigned char)(v & 0xff), (unsigned char)(v >> 8));
+  }
+  return *p;
+}
+
+template <int TPR, bool DOT>
 __device__ __forceinline__ void spmv_reduce_rows(const double *prod, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx,
                                                  const double *__restrict__ yin, double *__restrict__ yout, int r0, int r1, int abase,
-                                                 bool add, bool cprow)
+                                                 bool add, bool cprow, const double *__restrict__ dotv, double &dacc)
 {
   const int t = threadIdx.x;
   constexpr int RPP = PHIP_THREADS / TPR; /* rows per pass */
@@ -85,9 +110,11 @@ __device__ __forceinline__ void spmv_reduce_rows(const double *prod, const int32
     if (TPR == 1) {
       if (valid) {
         rout = cprow ? ridx[r] : r;
-        if (add) sum = yin[rout];
+        const double y0 = add ? yin[rout] : 0.0;
+        sum = y0;
         for (int j = s; j < e; j++) sum += prod[j];
         yout[rout] = sum;
+        if (DOT) dacc += dotv[rout] * (add ? sum - y0 : sum);
       }
     } else {
       for (int j = s + sub; j < e; j += TPR) sum += prod[j];
@@ -95,6 +122,7 @@ __device__ __forceinline__ void spmv_reduce_rows(const double *prod, const int32
       for (int o = TPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
       if (valid && sub == 0) {
         rout = cprow ? ridx[r] : r;
+        if (DOT) dacc += dotv[rout] * sum;
         if (add) sum += yin[rout];
         yout[rout] = sum;
       }
@@ -102,121 +130,149 @@ __device__ __forceinline__ void spmv_reduce_rows(const double *prod, const int32
   }
 }
 
-__global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(const int32_t *__restrict__ blkrow, const uint8_t *__restrict__ blktpr,
+/* DOT: also accumulate sum_i dotv[i] * (A x)_i (the increment, for MultAdd) and leave it where ctl says; the grid then strides over
+   the row blocks with at most PHIP_RED_BLOCKS workgroups.  Without DOT the grid is one workgroup per row block. */
+template <bool DOT>
+__global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(int32_t nblocks, const int32_t *__restrict__ blkrow, const uint8_t *__restrict__ blktpr,
                                                                      const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx,
                                                                      const int32_t *__restrict__ col, const double *__restrict__ val,
                                                                      const double *__restrict__ x, const double *__restrict__ yin,
-                                                                     double *__restrict__ yout, int add, int cprow)
+                                                                     double *__restrict__ yout, int add, int cprow, const double *__restrict__ dotv, RedCtl ctl)
 {
   __shared__ __attribute__((aligned(16))) double prod[2 * SPMV_PAIRS];
   const int t = threadIdx.x;
-  const int b = blockIdx.x;
-  const int r0 = blkrow[b], r1 = blkrow[b + 1];
-  const int base = rowptr[r0], end = rowptr[r1];
+  double    dacc = 0.0;
+  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const int r0 = blkrow[b], r1 = blkrow[b + 1];
+    const int base = rowptr[r0], end = rowptr[r1];
 
-  if (end - base > SPMV_CAP) {
-    /* one long row (the plan guarantees r1 == r0 + 1): whole workgroup strides over it */
-    double sum = 0.0;
-    for (int j = base + t; j < end; j += PHIP_THREADS) sum += val[j] * x[col[j]];
+    if (end - base > SPMV_CAP) {
+      /* one long row (the plan guarantees r1 == r0 + 1): whole workgroup strides over it */
+      double sum = 0.0;
+      for (int j = base + t; j < end; j += PHIP_THREADS) sum += val[j] * x[col[j]];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    if ((t & 63) == 0) prod[t >> 6] = sum;
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      if ((t & 63) == 0) prod[t >> 6] = sum;
+      __syncthreads();
+      if (t == 0) {
+        const int rout = cprow ? ridx[r0] : r0;
+        double    s = (prod[0] + prod[1]) + (prod[2] + prod[3]);
+        if (DOT) dacc += dotv[rout] * s;
+        if (add) s += yin[rout];
+        yout[rout] = s;
+      }
+    } else {
+      /* phase 1: stream products into LDS.  abase is even so val pairs are 16-byte aligned. */
+      const int abase = base & ~1;
+      double2   a[4];
+      int2      c[4];
+      bool      v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int e = abase + 2 * (t + k * PHIP_THREADS);
+        v[k] = e < end;
+        if (v[k]) {
+          a[k] = *reinterpret_cast<const double2 *>(val + e);
+          c[k] = *reinterpret_cast<const int2 *>(col + e);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (v[k]) {
+          double2 p;
+          p.x = a[k].x * x[c[k].x];
+          p.y = a[k].y * x[c[k].y];
+          *reinterpret_cast<double2 *>(prod + 2 * (t + k * PHIP_THREADS)) = p;
+        }
+      }
+      __syncthreads();
+
+      /* phase 2: per-row sums out of LDS */
+      switch (blktpr[b]) {
+      case 0: spmv_reduce_rows<1, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc); break;
+      case 1: spmv_reduce_rows<2, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc); break;
+      case 2: spmv_reduce_rows<4, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc); break;
+      case 3: spmv_reduce_rows<8, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc); break;
+      case 4: spmv_reduce_rows<16, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc); break;
+      case 5: spmv_reduce_rows<32, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc); break;
+      default: spmv_reduce_rows<64, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc); break;
+      }
+    }
+    if (DOT) __syncthreads(); /* the next row block of this workgroup reuses prod[] */
+  }
+  if (DOT) {
+    double a1[1] = {dacc};
+    block_sum<1>(a1, prod);
     __syncthreads();
-    if (t == 0) {
-      const int rout = cprow ? ridx[r0] : r0;
-      double    s = (prod[0] + prod[1]) + (prod[2] + prod[3]);
-      if (add) s += yin[rout];
-      yout[rout] = s;
-    }
-    return;
-  }
-
-  /* phase 1: stream products into LDS.  abase is even so val pairs are 16-byte aligned. */
-  const int abase = base & ~1;
-  double2   a[4];
-  int2      c[4];
-  bool      v[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int e = abase + 2 * (t + k * PHIP_THREADS);
-    v[k] = e < end;
-    if (v[k]) {
-      a[k] = *reinterpret_cast<const double2 *>(val + e);
-      c[k] = *reinterpret_cast<const int2 *>(col + e);
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    if (v[k]) {
-      double2 p;
-      p.x = a[k].x * x[c[k].x];
-      p.y = a[k].y * x[c[k].y];
-      *reinterpret_cast<double2 *>(prod + 2 * (t + k * PHIP_THREADS)) = p;
-    }
-  }
-  __syncthreads();
-
-  /* phase 2: per-row sums out of LDS */
-  switch (blktpr[b]) {
-  case 0: spmv_reduce_rows<1>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow); break;
-  case 1: spmv_reduce_rows<2>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow); break;
-  case 2: spmv_reduce_rows<4>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow); break;
-  case 3: spmv_reduce_rows<8>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow); break;
-  case 4: spmv_reduce_rows<16>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow); break;
-  case 5: spmv_reduce_rows<32>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow); break;
-  default: spmv_reduce_rows<64>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow); break;
+    reduce_tail<1, 0>(a1, prod, ctl);
   }
 }
 
-
-/* SELL-dict SpMV: see the header comment.  Lane t of slice b owns rows 512 b + 2 t and + 1. */
-__global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int32_t n, const int64_t *__restrict__ sptr, const uint8_t *__restrict__ slen,
+/* SELL-dict SpMV: see the header comment.  Lane t of slice b owns rows 512 b + 2 t and + 1.  DOT as in spmv_rowblock_kernel. */
+template <bool NT, bool DOT>
+__global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int32_t nslices, const int64_t *__restrict__ sptr, const uint8_t *__restrict__ slen,
                                                                  const double *__restrict__ sval, const uint8_t *__restrict__ scode,
                                                                  const int32_t *__restrict__ soffs, int noffs, const double *__restrict__ x,
-                                                                 const double *__restrict__ yin, double *__restrict__ yout, int add)
+                                                                 const double *__restrict__ yin, double *__restrict__ yout, int add,
+                                                                 const double *__restrict__ dotv, RedCtl ctl)
 {
 #pragma clang fp contract(off) /* multiply and add round separately, as the reference's compiled loop does (no FMA) */
   __shared__ int32_t offs[SELL_MAX_OFFS];
+  __shared__ double  lds[4];
   const int t = threadIdx.x;
   offs[t] = (t < noffs) ? soffs[t] : 0;
   __syncthreads();
-  const int r0 = blockIdx.x * SELL_H + 2 * t;
-  if (r0 >= m) return;
-  const bool has1 = r0 + 1 < m;
-  const int  l0 = slen[r0], l1 = has1 ? slen[r0 + 1] : 0;
-  const int  lm = l0 > l1 ? l0 : l1;
-  const int64_t  base = sptr[blockIdx.x];
-  const double2 *vp = reinterpret_cast<const double2 *>(sval + base) + t;
-  const uchar2  *cp = reinterpret_cast<const uchar2 *>(scode + base) + t;
-  double s0 = 0.0, s1 = 0.0;
-  if (add) { s0 = yin[r0]; if (has1) s1 = yin[r0 + 1]; }
-  int s = 0;
-  for (; s + 4 <= lm; s += 4) {
-    double2 v[4];
-    uchar2  c[4];
+  double dacc = 0.0;
+  for (int b = blockIdx.x; b < nslices; b += gridDim.x) {
+    const int r0 = b * SELL_H + 2 * t;
+    if (r0 >= m) continue;
+    const bool has1 = r0 + 1 < m;
+    const int  l0 = slen[r0], l1 = has1 ? slen[r0 + 1] : 0;
+    const int  lm = l0 > l1 ? l0 : l1;
+    const int64_t  base = sptr[b];
+    const double2 *vp = reinterpret_cast<const double2 *>(sval + base) + t;
+    const uchar2  *cp = reinterpret_cast<const uchar2 *>(scode + base) + t;
+    double y0 = 0.0, y1 = 0.0;
+    if (add) { y0 = yin[r0]; if (has1) y1 = yin[r0 + 1]; }
+    double s0 = y0, s1 = y1;
+    int    s = 0;
+    for (; s + 4 <= lm; s += 4) {
+      double2 v[4];
+      uchar2  c[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { v[u] = vp[(size_t)(s + u) * (SELL_H / 2)]; c[u] = cp[(size_t)(s + u) * (SELL_H / 2)]; }
-    double xa[4], xb[4];
+      for (int u = 0; u < 4; u++) { v[u] = ld_stream<NT>(vp + (size_t)(s + u) * (SELL_H / 2)); c[u] = ld_stream<NT>(cp + (size_t)(s + u) * (SELL_H / 2)); }
+      double xa[4], xb[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const bool a0 = s + u < l0, a1 = s + u < l1;
-      xa[u] = x[a0 ? r0 + offs[c[u].x] : 0];
-      xb[u] = x[a1 ? r0 + 1 + offs[c[u].y] : 0];
+      for (int u = 0; u < 4; u++) {
+        const bool a0 = s + u < l0, a1 = s + u < l1;
+        xa[u] = x[a0 ? r0 + offs[c[u].x] : 0];
+        xb[u] = x[a1 ? r0 + 1 + offs[c[u].y] : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (s + u < l0) s0 = s0 + v[u].x * xa[u];
+        if (s + u < l1) s1 = s1 + v[u].y * xb[u];
+      }
     }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (s + u < l0) s0 = s0 + v[u].x * xa[u];
-      if (s + u < l1) s1 = s1 + v[u].y * xb[u];
+    for (; s < lm; s++) {
+      const double2 v = ld_stream<NT>(vp + (size_t)s * (SELL_H / 2));
+      const uchar2  c = ld_stream<NT>(cp + (size_t)s * (SELL_H / 2));
+      if (s < l0) s0 = s0 + v.x * x[r0 + offs[c.x]];
+      if (s < l1) s1 = s1 + v.y * x[r0 + 1 + offs[c.y]];
+    }
+    if (has1) *reinterpret_cast<double2 *>(yout + r0) = make_double2(s0, s1);
+    else yout[r0] = s0;
+    if (DOT) {
+      dacc += dotv[r0] * (s0 - y0);
+      if (has1) dacc += dotv[r0 + 1] * (s1 - y1);
     }
   }
-  for (; s < lm; s++) {
-    const double2 v = vp[(size_t)s * (SELL_H / 2)];
-    const uchar2  c = cp[(size_t)s * (SELL_H / 2)];
-    if (s < l0) s0 = s0 + v.x * x[r0 + offs[c.x]];
-    if (s < l1) s1 = s1 + v.y * x[r0 + 1 + offs[c.y]];
+  if (DOT) {
+    double a1[1] = {dacc};
+    block_sum<1>(a1, lds);
+    __syncthreads();
+    reduce_tail<1, 0>(a1, lds, ctl);
   }
-  if (has1) *reinterpret_cast<double2 *>(yout + r0) = make_double2(s0, s1);
-  else yout[r0] = s0;
 }
 
 __global__ void getdiag_kernel(int32_t m, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx, int32_t R,
@@ -488,6 +544,27 @@ extern "C" int phip_mat_destroy(phip_mat A)
   return 0;
 }
 
+template <bool DOT>
+static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, double *d_yout, int add, const double *d_v, const RedCtl &ctl)
+{
+  hipStream_t st = A->ctx->stream;
+  if (A->sell_on) {
+    const unsigned grid = DOT ? (unsigned)(A->sell_nslices < PHIP_RED_BLOCKS ? A->sell_nslices : PHIP_RED_BLOCKS) : (unsigned)A->sell_nslices;
+    if (9 * A->sell_padded > PHIP_NT_MATRIX_BYTES)
+      hipLaunchKernelGGL((spmv_sell_kernel<true, DOT>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->m, A->sell_nslices, A->d_sptr, A->d_slen, A->d_sval, A->d_scode,
+                         A->d_soffs, A->sell_noffs, d_x, d_yin, d_yout, add, d_v, ctl);
+    else
+      hipLaunchKernelGGL((spmv_sell_kernel<false, DOT>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->m, A->sell_nslices, A->d_sptr, A->d_slen, A->d_sval, A->d_scode,
+                         A->d_soffs, A->sell_noffs, d_x, d_yin, d_yout, add, d_v, ctl);
+  } else {
+    const unsigned grid = DOT ? (unsigned)(A->nblocks < PHIP_RED_BLOCKS ? (A->nblocks > 0 ? A->nblocks : 1) : PHIP_RED_BLOCKS) : (unsigned)A->nblocks;
+    hipLaunchKernelGGL((spmv_rowblock_kernel<DOT>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->nblocks, A->d_blkrow, A->d_blktpr, A->d_rowptr, A->d_ridx, A->d_col,
+                       A->d_val, d_x, d_yin, d_yout, add, A->use_cprow, d_v, ctl);
+  }
+  PHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 static int launch_spmv(phip_mat A, const double *d_x, const double *d_yin, double *d_yout, int add)
 {
   if (!A->nblocks) return 0;
@@ -497,13 +574,24 @@ static int launch_spmv(phip_mat A, const double *d_x, const double *d_yin, doubl
     if (rc) return rc;
     PHIP_CHECK_HIP(hipEventRecord(e0, A->ctx->stream));
   }
-  if (A->sell_on)
-    hipLaunchKernelGGL(spmv_sell_kernel, dim3((unsigned)A->sell_nslices), dim3(PHIP_THREADS), 0, A->ctx->stream, A->m, A->n, A->d_sptr, A->d_slen, A->d_sval,
-                       A->d_scode, A->d_soffs, A->sell_noffs, d_x, d_yin, d_yout, add);
-  else
-    hipLaunchKernelGGL(spmv_rowblock_kernel, dim3((unsigned)A->nblocks), dim3(PHIP_THREADS), 0, A->ctx->stream, A->d_blkrow, A->d_blktpr, A->d_rowptr,
-                       A->d_ridx, A->d_col, A->d_val, d_x, d_yin, d_yout, add, A->use_cprow);
-  PHIP_CHECK_HIP(hipGetLastError());
+  RedCtl none;
+  memset(&none, 0, sizeof(none));
+  int rc = launch_spmv_t<false>(A, d_x, d_yin, d_yout, add, NULL, none);
+  if (rc) return rc;
+  if (e1) PHIP_CHECK_HIP(hipEventRecord(e1, A->ctx->stream));
+  return 0;
+}
+
+static int launch_spmv_dot(phip_mat A, const double *d_x, const double *d_yin, double *d_yout, int add, const double *d_v, const RedCtl &ctl)
+{
+  hipEvent_t e0 = NULL, e1 = NULL;
+  if (A->ctx->prof_on) {
+    int rc = phip_prof_open(A->ctx, add ? 1 : 0, &e0, &e1);
+    if (rc) return rc;
+    PHIP_CHECK_HIP(hipEventRecord(e0, A->ctx->stream));
+  }
+  int rc = launch_spmv_t<true>(A, d_x, d_yin, d_yout, add, d_v, ctl); /* runs even for an empty matrix: the tail must publish 0 */
+  if (rc) return rc;
   if (e1) PHIP_CHECK_HIP(hipEventRecord(e1, A->ctx->stream));
   return 0;
 }
@@ -525,6 +613,29 @@ extern "C" int phip_mat_multadd(phip_mat A, const double *d_x, const double *d_y
   if (A->use_cprow && d_z != d_y && A->m)
     PHIP_CHECK_HIP(hipMemcpyAsync(d_z, d_y, sizeof(double) * (size_t)A->m, hipMemcpyDeviceToDevice, A->ctx->stream)); /* aij.c:1460-1462 */
   return launch_spmv(A, d_x, d_y, d_z, 1);
+}
+
+extern "C" int phip_mat_mult_dot(phip_mat A, const double *d_x, double *d_y, const double *d_v, int publish, phip_ticket *t)
+{
+  PHIP_REQUIRE(A && t && (d_y || !A->m) && (d_v || !A->m) && (d_x || !A->nnz), PHIP_ERR_ARG_NULL, "phip_mat_mult_dot: null argument");
+  PHIP_NEED_DEVICE(A->ctx, "phip_mat_mult_dot");
+  PHIP_REQUIRE(d_x != d_y || !A->m, PHIP_ERR_ARG_SIZ, "phip_mat_mult_dot: x and y must be different vectors (matrix.c:2213)");
+  if (A->use_cprow && A->m) PHIP_CHECK_HIP(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)A->m, A->ctx->stream)); /* aij.c:1296 */
+  RedCtl ctl;
+  int    rc = phip_ticket_open(A->ctx, 1, publish, t, &ctl);
+  if (rc) return rc;
+  return launch_spmv_dot(A, d_x, NULL, d_y, 0, d_v, ctl);
+}
+
+extern "C" int phip_mat_multadd_dot(phip_mat A, const double *d_x, double *d_y, const double *d_v, const phip_ticket *t)
+{
+  PHIP_REQUIRE(A && t && ((d_y && d_v) || !A->m) && (d_x || !A->nnz), PHIP_ERR_ARG_NULL, "phip_mat_multadd_dot: null argument");
+  PHIP_NEED_DEVICE(A->ctx, "phip_mat_multadd_dot");
+  PHIP_REQUIRE(d_x != d_y || !A->m, PHIP_ERR_ARG_SIZ, "phip_mat_multadd_dot: x and y must be different vectors");
+  RedCtl ctl;
+  int    rc = phip_ticket_accumulate(A->ctx, t, &ctl);
+  if (rc) return rc;
+  return launch_spmv_dot(A, d_x, d_y, d_y, 1, d_v, ctl);
 }
 
 extern "C" int phip_mat_getdiagonal(phip_mat A, double *d_v)

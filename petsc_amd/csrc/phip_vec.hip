@@ -19,124 +19,7 @@ struct MVPack {
 };
 
 /* where a reduction launch leaves its results */
-struct RedCtl {
-  double             *partial; /* [PHIP_MAX_MVEC][PHIP_RED_BLOCKS] */
-  unsigned int       *ticket;  /* arrival counters [33][32] (one used word per 128-byte line), zero on entry and on exit */
-  double             *d_out;   /* device results, indexed like the partial rows */
-  double             *h_slot;  /* pinned host slot (device address) or NULL: publish d_out[0..npub) there ... */
-  unsigned long long *h_seq;   /* ... then store seq here */
-  unsigned long long  seq;
-  int                 npub;
-  int                 kofs;    /* first partial row / d_out index of this launch */
-};
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ double wave_max(double v)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
-/* block-level sum of NV values; result valid in thread 0 */
-template <int NV>
-__device__ __forceinline__ void block_sum(double (&acc)[NV], double *lds /* [4*NV] */)
-{
-  const int t = threadIdx.x;
-#pragma unroll
-  for (int k = 0; k < NV; k++) acc[k] = wave_sum(acc[k]);
-  if ((t & 63) == 0) {
-#pragma unroll
-    for (int k = 0; k < NV; k++) lds[(t >> 6) * NV + k] = acc[k];
-  }
-  __syncthreads();
-  if (t == 0) {
-#pragma unroll
-    for (int k = 0; k < NV; k++) acc[k] = (lds[k] + lds[NV + k]) + (lds[2 * NV + k] + lds[3 * NV + k]);
-  }
-}
-
-/* Tail of every reduction kernel.  acc[] holds the workgroup's partials in thread 0.  MODE 0: NV sums.  MODE 1: acc[0] = max,
-   acc[1] = NaN flag -> one result (NaN if any flag, bvec2.c:253-258). */
-template <int NV, int MODE>
-__device__ __forceinline__ void reduce_tail(double (&acc)[NV], double *lds /* >= 4 doubles */, const RedCtl c)
-{
-  __shared__ int s_last;
-  const int      t = threadIdx.x;
-  const int      nb = gridDim.x;
-  if (t == 0) {
-#pragma unroll
-    for (int k = 0; k < NV; k++) __hip_atomic_store(&c.partial[(size_t)(c.kofs + k) * PHIP_RED_BLOCKS + blockIdx.x], acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    /* two-level arrival count: 32 workgroups per group counter (each on a 128-byte line of its own), then one top counter, so that
-       no word takes more than 32 serialised atomics (~12 ns each on one address); the last arrivers put the counters back to zero */
-    const int          g = blockIdx.x >> 5;
-    const unsigned int gsize = (unsigned int)((nb - (g << 5)) < 32 ? (nb - (g << 5)) : 32);
-    int                last = 0;
-    const unsigned int tk = __hip_atomic_fetch_add(&c.ticket[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tk == gsize - 1) {
-      __hip_atomic_store(&c.ticket[g * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned int ngroups = (unsigned int)((nb + 31) >> 5);
-      const unsigned int tk2 = __hip_atomic_fetch_add(&c.ticket[32 * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tk2 == ngroups - 1) {
-        __hip_atomic_store(&c.ticket[32 * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = 1;
-      }
-    }
-    s_last = last;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  /* last workgroup: wave w sums partial rows w, w+4, ...: 16 values per lane in index order, then the 64-lane tree (a fixed order
-     for a given grid, whichever workgroup arrives last); all of a row's loads are in flight at once */
-  const int w = t >> 6, lane = t & 63;
-  if (MODE == 1) {
-    if (w == 0) {
-      double m = 0.0, f = 0.0;
-#pragma unroll
-      for (int j = 0; j < PHIP_RED_BLOCKS / 64; j++) {
-        const int i = lane + 64 * j;
-        if (i < nb) {
-          m = fmax(m, __hip_atomic_load(&c.partial[(size_t)c.kofs * PHIP_RED_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          f = fmax(f, __hip_atomic_load(&c.partial[(size_t)(c.kofs + 1) * PHIP_RED_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
-      }
-      m = wave_max(m); f = wave_max(f);
-      if (lane == 0) c.d_out[c.kofs] = (f > 0.0) ? __builtin_nan("") : m;
-    }
-  } else {
-    for (int k = w; k < NV; k += PHIP_THREADS / 64) {
-      const double *row = c.partial + (size_t)(c.kofs + k) * PHIP_RED_BLOCKS;
-      double        v[PHIP_RED_BLOCKS / 64];
-#pragma unroll
-      for (int j = 0; j < PHIP_RED_BLOCKS / 64; j++) {
-        const int i = lane + 64 * j;
-        v[j] = (i < nb) ? __hip_atomic_load(&row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-      }
-      double s = 0.0;
-#pragma unroll
-      for (int j = 0; j < PHIP_RED_BLOCKS / 64; j++) s += v[j];
-      s = wave_sum(s);
-      if (lane == 0) c.d_out[c.kofs + k] = s;
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (t == 0) {
-    if (c.h_slot) {
-      /* d_out[0..kofs) came from earlier launches of the same call (earlier kernels on this stream), the rest from the stores above */
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      for (int k = 0; k < c.npub; k++) c.h_slot[k] = __hip_atomic_load(&c.d_out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence_system();
-      __hip_atomic_store(c.h_seq, c.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
+#include "phip_reduce.h"
 
 /* z[k] = sum_i x_i * y_k,i  for k < NV : x is read once per launch.  partial layout: [k][block] */
 template <int NV>
@@ -307,6 +190,34 @@ __global__ __launch_bounds__(PHIP_THREADS) void jacobi_setup_kernel(int32_t n, d
   if (zero) atomicOr(flag, 1);
 }
 
+/* w = x .* y with the by-products {sum w^2, sum w x, sum w y} (PCApply_Jacobi followed by VecNorm(Z) and VecTDot(Z,R), cg.c:225-269) */
+__global__ __launch_bounds__(PHIP_THREADS) void pmult_reduce_kernel(int32_t n, double *__restrict__ w, const double *__restrict__ x,
+                                                                    const double *__restrict__ y, RedCtl ctl)
+{
+  __shared__ double lds[12];
+  double            acc[3] = {0.0, 0.0, 0.0};
+  const int64_t     n2 = n >> 1;
+  const int64_t     stride = (int64_t)gridDim.x * PHIP_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; i < n2; i += stride) {
+    const double2 xv = reinterpret_cast<const double2 *>(x)[i];
+    const double2 yv = reinterpret_cast<const double2 *>(y)[i];
+    double2       o;
+    o.x = xv.x * yv.x; o.y = xv.y * yv.y;
+    reinterpret_cast<double2 *>(w)[i] = o;
+    acc[0] += o.x * o.x + o.y * o.y;
+    acc[1] += o.x * xv.x + o.y * xv.y;
+    acc[2] += o.x * yv.x + o.y * yv.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double o = x[n - 1] * y[n - 1];
+    w[n - 1] = o;
+    acc[0] += o * o; acc[1] += o * x[n - 1]; acc[2] += o * y[n - 1];
+  }
+  block_sum<3>(acc, lds);
+  __syncthreads();
+  reduce_tail<3, 0>(acc, lds, ctl);
+}
+
 /* ---- host launchers ---------------------------------------------------------------------------- */
 #define EW_GRID(n) phip_grid_for((n) / 2 + 1, 4, 2048)
 #define CHECK_CTX(c, name) do { PHIP_REQUIRE((c), PHIP_ERR_ARG_NULL, name ": null context"); PHIP_NEED_DEVICE((c), name); } while (0)
@@ -393,6 +304,19 @@ extern "C" int phip_vec_pointwise_mult(phip_ctx c, int32_t n, double *d_w, const
   return launch_ew<EW_PMULT, true, true, false>(c, n, d_w, d_x, d_y, NULL, 0, 0, 0); /* aliasing w==x / w==y is safe: pure elementwise */
 }
 
+extern "C" int phip_vec_pointwise_mult_reduce(phip_ctx c, int32_t n, double *d_w, const double *d_x, const double *d_y, int publish, phip_ticket *t)
+{
+  CHECK_CTX(c, "phip_vec_pointwise_mult_reduce"); CHECK_N(n, "phip_vec_pointwise_mult_reduce");
+  PHIP_REQUIRE(t, PHIP_ERR_ARG_NULL, "phip_vec_pointwise_mult_reduce: null ticket");
+  PHIP_REQUIRE((d_w != d_x && d_w != d_y) || !n, PHIP_ERR_ARG_WRONG, "phip_vec_pointwise_mult_reduce: w must not alias x or y (use phip_vec_pointwise_mult)");
+  RedCtl ctl;
+  int    rc = phip_ticket_open(c, 3, publish, t, &ctl);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pmult_reduce_kernel, dim3(phip_grid_for((int64_t)n / 2 + 1, 4, PHIP_RED_BLOCKS)), dim3(PHIP_THREADS), 0, c->stream, n, d_w, d_x, d_y, ctl);
+  PHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int phip_vec_pointwise_divide(phip_ctx c, int32_t n, double *d_w, const double *d_x, const double *d_y)
 {
   CHECK_CTX(c, "phip_vec_pointwise_divide"); CHECK_N(n, "phip_vec_pointwise_divide");
@@ -444,7 +368,7 @@ static int reduce_launch(phip_ctx c, int kind, int32_t n, const double *d_x, int
 {
   const int grid = reduce_grid(n);
   RedCtl    ctl;
-  ctl.partial = c->d_partials; ctl.ticket = c->d_ticket; ctl.d_out = d_out; ctl.h_slot = NULL; ctl.h_seq = NULL; ctl.seq = 0; ctl.npub = 0; ctl.kofs = 0;
+  ctl.partial = c->d_partials; ctl.ticket = c->d_ticket; ctl.d_out = d_out; ctl.h_slot = NULL; ctl.h_seq = NULL; ctl.seq = 0; ctl.npub = 0; ctl.kofs = 0; ctl.accumulate = 0;
   if (kind == 0) {
     PHIP_REQUIRE(nv >= 0 && nv <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_reduce_local: nv=%d (max %d)", nv, PHIP_MAX_MVEC);
     PHIP_REQUIRE(h_dy || !nv, PHIP_ERR_ARG_NULL, "phip_vec_reduce_local: null vector list");

@@ -185,6 +185,9 @@ class Comm:
         c.h, c.rank, c.size, c.self_h, c.ctx = self.self_h, 0, 1, self.self_h, self.ctx
         return c
 
+    def set_byproducts(self, flg):
+        chk(lib().PetscHipSetByProducts(self.h, 1 if flg else 0))
+
     def finalize(self):
         if self.h:
             chk(lib().PetscHipFinalize(C.byref(self.h)))

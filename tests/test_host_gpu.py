@@ -452,3 +452,50 @@ def test_full_size_properties(orc):
         return True
 
     assert run_ranks(1, body)[0]
+
+
+@pytest.mark.parametrize("size", [1, 2, 3])
+def test_byproduct_cache(orc, size):
+    """VecTDot(P,W) after MatMult(A,P,W), VecNorm(Z) and VecTDot(Z,R) after VecPointwiseMult(Z,R,D) are served from by-products
+    of the producing kernels; any later write to an operand invalidates them; results agree with the stand-alone kernels."""
+    from petsc_amd import generators as G, petsc as P
+    ai, aj, aa = G.laplace3d_7pt(11, 9, 13, dirichlet_rows=False)
+    N = len(ai) - 1
+    xg = G.random_vector(N)
+
+    def body(comm):
+        rs, re = local_slice(comm, N)
+        A = P.Mat.from_global_csr(comm, ai, aj, aa)
+        x = P.Vec.from_array(comm, xg[rs:re], N)
+        y, z, d = x.duplicate(), x.duplicate(), x.duplicate()
+        d.set_array(np.linspace(0.5, 1.5, N)[rs:re])
+        out = {}
+        for on in (True, False):
+            comm.set_byproducts(on)
+            A.mult(x, y)
+            out["xy", on] = x.dot(y)
+            out["yx", on] = y.tdot(x)
+            z.pointwise_mult(y, d)
+            out["nz", on] = z.norm()
+            out["zy", on] = z.tdot(y)
+            out["dz", on] = d.dot(z)
+            # writes invalidate: after scaling y, dot(x, y) must be the new value
+            y.scale(2.0)
+            out["xy2", on] = x.dot(y)
+            out["zy2", on] = z.dot(y)
+            z.axpy(1.0, y)
+            out["nz2", on] = z.norm()
+        comm.set_byproducts(True)
+        for o in (x, y, z, d, A):
+            o.destroy()
+        return out
+
+    res = run_ranks(size, body)[0]
+    yo = orc.operator(ai, aj, aa, 1).mult(xg)
+    dg = np.linspace(0.5, 1.5, N)
+    zo = yo * dg
+    ref = {"xy": xg @ yo, "yx": xg @ yo, "nz": np.linalg.norm(zo), "zy": zo @ yo, "dz": dg @ zo, "xy2": 2 * (xg @ yo), "zy2": 2 * (zo @ yo),
+           "nz2": np.linalg.norm(zo + 2 * yo)}
+    for key, val in ref.items():
+        for on in (True, False):
+            assert abs(res[key, on] - val) <= 1e-12 * max(abs(val), 1.0), (key, on, res[key, on], val)

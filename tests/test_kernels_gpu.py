@@ -360,3 +360,74 @@ def test_rccl_single_rank(ctx):
     assert gathered[0] == 42
     ctx.check(ctx.lib.phip_comm_destroy(comm))
     ctx.free(dbuf)
+
+
+def test_byproduct_tickets(ctx, orc):
+    """Reductions fused into the producing kernel: w = x.*y with {sum w^2, sum w x, sum w y}; y = A x with sum v_i y_i; the
+    off-diagonal block's MultAdd adding sum v_i (increment)_i to the same ticket; expiry of old tickets."""
+    import ctypes as C
+    from petsc_amd import generators as G
+    from petsc_amd.capi import Ticket, PhipError
+    L = ctx.lib
+    rng = np.random.default_rng(21)
+    for n in (0, 1, 7, 1000, 300001):
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        dx, dy, dw = ctx.to_device(x if n else np.zeros(1)), ctx.to_device(y if n else np.zeros(1)), ctx.to_device(np.zeros(max(n, 1)))
+        t = Ticket()
+        ctx.check(L.phip_vec_pointwise_mult_reduce(ctx.h, n, dw, dx, dy, 1, C.byref(t)))
+        vals = np.zeros(3)
+        ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t), vals.ctypes.data_as(C.POINTER(C.c_double))))
+        w = x * y
+        np.testing.assert_array_equal(ctx.to_host(dw, n), orc.pointwisemult(x, y))
+        ref = np.array([w @ w, w @ x, w @ y])
+        assert np.abs(vals - ref).max() <= 1e-13 * max(1.0, np.abs(w * w).sum(), np.abs(w * x).sum(), np.abs(w * y).sum())
+        # the same values through the device slot (the multi-rank consumption path)
+        dv = C.c_void_p()
+        ctx.check(L.phip_ticket_values(ctx.h, C.byref(t), C.byref(dv)))
+        np.testing.assert_array_equal(ctx.to_host(dv, 3), vals)
+        with pytest.raises(PhipError):  # aliasing is refused: the plain kernel handles it
+            ctx.check(L.phip_vec_pointwise_mult_reduce(ctx.h, n or 1, dx, dx, dy, 1, C.byref(t)))
+        for p in (dx, dy, dw):
+            ctx.free(p)
+    cases = [G.laplace3d_7pt(24), G.box3d_27pt(13), G.rmat(12), G.laplace2d_5pt(3, 2)]
+    for ai, aj, aa in cases:
+        n = len(ai) - 1
+        x, v = G.random_vector(n), rng.standard_normal(n)
+        for fmt in (1, 2):
+            A = ctx.mat_create(n, n, ai, aj, aa)
+            if L.phip_mat_set_format(A, fmt) != 0:
+                ctx.check(L.phip_mat_destroy(A))
+                continue
+            dx, dv, dy = ctx.to_device(x), ctx.to_device(v), ctx.to_device(np.zeros(n))
+            t = Ticket()
+            ctx.check(L.phip_mat_mult_dot(A, dx, dy, dv, 1, C.byref(t)))
+            val = np.zeros(1)
+            ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t), val.ctypes.data_as(C.POINTER(C.c_double))))
+            yo = orc.matmult(ai, aj, aa, x)
+            assert relerr(ctx.to_host(dy, n), yo) <= 1e-12
+            assert abs(val[0] - v @ yo) <= 1e-12 * np.abs(v * yo).sum()
+            # MultAdd in place adds its increment's share to the same ticket (no publish: read the device slot)
+            t2 = Ticket()
+            ctx.check(L.phip_mat_mult_dot(A, dx, dy, dv, 0, C.byref(t2)))
+            ctx.check(L.phip_mat_multadd_dot(A, dx, dy, dv, C.byref(t2)))
+            dvp = C.c_void_p()
+            ctx.check(L.phip_ticket_values(ctx.h, C.byref(t2), C.byref(dvp)))
+            assert abs(ctx.to_host(dvp, 1)[0] - 2.0 * (v @ yo)) <= 1e-11 * np.abs(v * yo).sum()
+            assert relerr(ctx.to_host(dy, n), 2.0 * yo) <= 1e-12
+            for p in (dx, dv, dy):
+                ctx.free(p)
+            ctx.check(L.phip_mat_destroy(A))
+    # a ticket expires after 63 newer ones
+    dx = ctx.to_device(np.ones(8)); dw = ctx.to_device(np.zeros(8))
+    dy = ctx.to_device(np.full(8, 2.0))
+    first = Ticket()
+    ctx.check(L.phip_vec_pointwise_mult_reduce(ctx.h, 8, dw, dx, dy, 1, C.byref(first)))
+    t = Ticket()
+    for _ in range(64):
+        ctx.check(L.phip_vec_pointwise_mult_reduce(ctx.h, 8, dw, dx, dy, 1, C.byref(t)))
+    vals = np.zeros(3)
+    assert L.phip_ticket_wait(ctx.h, C.byref(first), vals.ctypes.data_as(C.POINTER(C.c_double))) == 73
+    ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t), vals.ctypes.data_as(C.POINTER(C.c_double))))
+    np.testing.assert_array_equal(vals, [32.0, 16.0, 32.0])
+    for p in (dx, dy, dw):
+        ctx.free(p)
