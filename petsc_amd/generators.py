@@ -90,32 +90,44 @@ def convdiff3d_7pt(nx, ny=None, nz=None, c=0.5, rstart=0, rend=None):
     return _stencil_csr((nx, ny, nz), offs, val, rstart, rend)
 
 
-def rmat(scale, edge_factor=16, a=0.57, b=0.19, c=0.19, seed=20240601, chunk=1 << 22):
+def rmat(scale, edge_factor=16, a=0.57, b=0.19, c=0.19, seed=20240601, chunk=1 << 23):
     """Config 5: R-MAT (a,b,c,d) power-law matrix, 2^scale rows, edge_factor*2^scale samples, duplicates summed,
-    self-loops kept, values uniform(0,1)."""
-    import scipy.sparse as sp
+    self-loops kept, values uniform(0,1).  Edges are drawn in chunks, keyed row*2^scale+col, sorted once and merged."""
     n = 1 << scale
     ne = edge_factor * n
     rng = np.random.default_rng(seed)
-    acc = None
+    keys = np.empty(ne, dtype=np.uint64)
+    vals = np.empty(ne, dtype=np.float64)
     done = 0
     while done < ne:
         cnt = min(chunk, ne - done)
-        r = np.zeros(cnt, dtype=np.int64)
-        cc = np.zeros(cnt, dtype=np.int64)
+        r = np.zeros(cnt, dtype=np.uint64)
+        cc = np.zeros(cnt, dtype=np.uint64)
         for _ in range(scale):
             u = rng.random(cnt)
             rbit = u >= a + b
             cbit = ((u >= a) & (u < a + b)) | (u >= a + b + c)
-            r = (r << 1) | rbit
-            cc = (cc << 1) | cbit
-        v = rng.random(cnt)
-        part = sp.coo_matrix((v, (r, cc)), shape=(n, n)).tocsr()
-        acc = part if acc is None else acc + part
+            r = (r << np.uint64(1)) | rbit.astype(np.uint64)
+            cc = (cc << np.uint64(1)) | cbit.astype(np.uint64)
+        keys[done:done + cnt] = (r << np.uint64(scale)) | cc
+        vals[done:done + cnt] = rng.random(cnt)
         done += cnt
-    acc.sum_duplicates()
-    acc.sort_indices()
-    return acc.indptr.astype(np.int32), acc.indices.astype(np.int32), acc.data.astype(np.float64)
+    order = np.argsort(keys, kind="stable")
+    keys = keys[order]
+    vals = vals[order]
+    del order
+    first = np.empty(ne, dtype=bool)
+    first[0] = True
+    np.not_equal(keys[1:], keys[:-1], out=first[1:])
+    starts = np.flatnonzero(first)
+    aa = np.add.reduceat(vals, starts)
+    ukeys = keys[starts]
+    del keys, vals, first
+    rows = (ukeys >> np.uint64(scale)).astype(np.int64)
+    aj = (ukeys & np.uint64(n - 1)).astype(np.int32)
+    ai = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=n), out=ai[1:])
+    return ai.astype(np.int32), aj, aa.astype(np.float64)
 
 
 def random_vector(n, seed=12345):

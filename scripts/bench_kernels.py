@@ -23,11 +23,21 @@ def main():
     ap.add_argument("--tpr", type=int, default=0)
     ap.add_argument("--vec", type=int, default=1)
     ap.add_argument("--fmt", type=int, default=0)
+    ap.add_argument("--rmat", type=int, default=0, help="R-MAT scale instead of a stencil")
     a = ap.parse_args()
     ctx = capi.Context(0)
     L = ctx.lib
     print(json.dumps(ctx.device_info()))
-    ai, aj, aa = (G.laplace3d_7pt if a.stencil == 7 else G.box3d_27pt)(a.grid)
+    if a.rmat:
+        cache = "/tmp/rmat_%d.npz" % a.rmat
+        if os.path.exists(cache):
+            z = np.load(cache)
+            ai, aj, aa = z["i"], z["j"], z["a"]
+        else:
+            ai, aj, aa = G.rmat(a.rmat)
+            np.savez(cache, i=ai, j=aj, a=aa)
+    else:
+        ai, aj, aa = (G.laplace3d_7pt if a.stencil == 7 else G.box3d_27pt)(a.grid)
     m = len(ai) - 1
     nz = len(aj)
     A = ctx.mat_create(m, m, ai, aj, aa)
