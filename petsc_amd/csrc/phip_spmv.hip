@@ -29,6 +29,7 @@
 #include "phip_internal.h"
 #include "phip_reduce.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <vector>
 
 #define SPMV_CAP 2046          /* nonzeros per row block; +2 alignment slack = 2048 LDS doubles = 16 KiB */
@@ -37,6 +38,9 @@
 #define SELL_H 512             /* rows per SELL slice = 2 rows per lane */
 #define SELL_MAX_OFFS 256
 #define SELL_MAX_PAD 1.15
+#define SELL_CL_SPAN 64         /* diagonals at most this far apart share one staged x segment */
+#define SELL_CL_MAX 32
+#define SELL_STAGE_MAX_BYTES (64 * 1024)
 
 static int g_default_fmt = 0; /* phip_set_default_mat_format */
 
@@ -63,6 +67,10 @@ struct phip_mat_s {
   uint8_t *d_scode, *d_slen;
   int64_t *d_sptr;
   int32_t *d_soffs;
+  /* LDS staging of x for the SELL-dict kernel: diagonals grouped into clusters of nearby offsets, one contiguous x segment per cluster */
+  int      stage_ok, stage_ncl, stage_lds_doubles;
+  int32_t *d_scl;     /* [ncl][3]: first offset of the cluster, start of its segment in LDS (doubles), segment length */
+  int32_t *d_sldsoff; /* [256]: LDS index of x[row + diagonal] for local row 0, per diagonal code */
   std::vector<int64_t> *h_sptr;
 };
 
@@ -218,32 +226,49 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(int32_t nbl
   }
 }
 
-/* SELL-dict SpMV: see the header comment.  Lane t of slice b owns rows 512 b + 2 t and + 1.  DOT as in spmv_rowblock_kernel. */
-template <bool NT, bool DOT>
-__global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int32_t nslices, const int64_t *__restrict__ sptr, const uint8_t *__restrict__ slen,
+/* SELL-dict SpMV: see the header comment.  Lane t of slice b owns rows 512 b + 2 t and + 1.  DOT as in spmv_rowblock_kernel.
+   STAGE: the x entries a slice needs form a few contiguous segments (one per cluster of nearby diagonals: 9 for a 27-point stencil);
+   the workgroup copies them into LDS with coalesced loads and gathers from there, so each x entry crosses L2 once per cluster
+   instead of once per diagonal and the per-lane gathers no longer thrash L1. */
+template <bool NT, bool DOT, bool STAGE>
+__global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int32_t n, int32_t nslices, const int64_t *__restrict__ sptr, const uint8_t *__restrict__ slen,
                                                                  const double *__restrict__ sval, const uint8_t *__restrict__ scode,
-                                                                 const int32_t *__restrict__ soffs, int noffs, const double *__restrict__ x,
-                                                                 const double *__restrict__ yin, double *__restrict__ yout, int add,
+                                                                 const int32_t *__restrict__ soffs, int noffs, const int32_t *__restrict__ scl, int ncl,
+                                                                 const double *__restrict__ x, const double *__restrict__ yin, double *__restrict__ yout, int add,
                                                                  const double *__restrict__ dotv, RedCtl ctl)
 {
 #pragma clang fp contract(off) /* multiply and add round separately, as the reference's compiled loop does (no FMA) */
-  __shared__ int32_t offs[SELL_MAX_OFFS];
+  extern __shared__ __attribute__((aligned(16))) double xs[]; /* STAGE: the x segments */
+  __shared__ int32_t offs[SELL_MAX_OFFS];                      /* diagonal (or, STAGE, LDS index) per code */
   __shared__ double  lds[4];
   const int t = threadIdx.x;
   offs[t] = (t < noffs) ? soffs[t] : 0;
   __syncthreads();
   double dacc = 0.0;
   for (int b = blockIdx.x; b < nslices; b += gridDim.x) {
-    const int r0 = b * SELL_H + 2 * t;
-    if (r0 >= m) continue;
+    if (STAGE) {
+      if (b != (int)blockIdx.x) __syncthreads(); /* the previous slice of this workgroup is done with xs[] */
+      for (int c = 0; c < ncl; c++) {
+        const int g0 = b * SELL_H + scl[3 * c], s0 = scl[3 * c + 1], len = scl[3 * c + 2];
+        for (int i = t; i < len; i += PHIP_THREADS) {
+          const int g = g0 + i;
+          xs[s0 + i] = (g >= 0 && g < n) ? x[g] : 0.0;
+        }
+      }
+      __syncthreads();
+    }
+    const int  r0 = b * SELL_H + 2 * t;
+    const bool act = r0 < m;
     const bool has1 = r0 + 1 < m;
-    const int  l0 = slen[r0], l1 = has1 ? slen[r0 + 1] : 0;
+    const int  l0 = act ? slen[r0] : 0, l1 = has1 ? slen[r0 + 1] : 0;
     const int  lm = l0 > l1 ? l0 : l1;
     const int64_t  base = sptr[b];
     const double2 *vp = reinterpret_cast<const double2 *>(sval + base) + t;
     const uchar2  *cp = reinterpret_cast<const uchar2 *>(scode + base) + t;
+    const int      g0 = STAGE ? 2 * t : r0; /* STAGE: index into xs[] relative to the slice, else global row */
+    const double  *xv = STAGE ? xs : x;
     double y0 = 0.0, y1 = 0.0;
-    if (add) { y0 = yin[r0]; if (has1) y1 = yin[r0 + 1]; }
+    if (add && act) { y0 = yin[r0]; if (has1) y1 = yin[r0 + 1]; }
     double s0 = y0, s1 = y1;
     int    s = 0;
     for (; s + 4 <= lm; s += 4) {
@@ -255,8 +280,8 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const bool a0 = s + u < l0, a1 = s + u < l1;
-        xa[u] = x[a0 ? r0 + offs[c[u].x] : 0];
-        xb[u] = x[a1 ? r0 + 1 + offs[c[u].y] : 0];
+        xa[u] = xv[a0 ? g0 + offs[c[u].x] : 0];
+        xb[u] = xv[a1 ? g0 + 1 + offs[c[u].y] : 0];
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -267,12 +292,12 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
     for (; s < lm; s++) {
       const double2 v = ld_stream<NT>(vp + (size_t)s * (SELL_H / 2));
       const uchar2  c = ld_stream<NT>(cp + (size_t)s * (SELL_H / 2));
-      if (s < l0) s0 = s0 + v.x * x[r0 + offs[c.x]];
-      if (s < l1) s1 = s1 + v.y * x[r0 + 1 + offs[c.y]];
+      if (s < l0) s0 = s0 + v.x * xv[g0 + offs[c.x]];
+      if (s < l1) s1 = s1 + v.y * xv[g0 + 1 + offs[c.y]];
     }
     if (has1) *reinterpret_cast<double2 *>(yout + r0) = make_double2(s0, s1);
-    else yout[r0] = s0;
-    if (DOT) {
+    else if (act) yout[r0] = s0;
+    if (DOT && act) {
       dacc += dotv[r0] * (s0 - y0);
       if (has1) dacc += dotv[r0 + 1] * (s1 - y1);
     }
@@ -408,8 +433,8 @@ static void fill_sell_values(const std::vector<int32_t> &rp, int32_t m, const do
 
 static void free_sell(phip_mat A)
 {
-  if (A->ctx->device >= 0) { hipFree(A->d_sval); hipFree(A->d_scode); hipFree(A->d_slen); hipFree(A->d_sptr); hipFree(A->d_soffs); }
-  A->d_sval = NULL; A->d_scode = NULL; A->d_slen = NULL; A->d_sptr = NULL; A->d_soffs = NULL;
+  if (A->ctx->device >= 0) { hipFree(A->d_sval); hipFree(A->d_scode); hipFree(A->d_slen); hipFree(A->d_sptr); hipFree(A->d_soffs); hipFree(A->d_scl); hipFree(A->d_sldsoff); }
+  A->d_sval = NULL; A->d_scode = NULL; A->d_slen = NULL; A->d_sptr = NULL; A->d_soffs = NULL; A->d_scl = NULL; A->d_sldsoff = NULL; A->stage_ok = 0;
   A->sell_on = 0; A->sell_built = 0;
 }
 
@@ -433,6 +458,29 @@ static int setup_sell(phip_mat A, const int32_t *h_j, const double *h_a)
   A->sell_noffs = (int32_t)soffs.size();
   A->sell_padded = (*A->h_sptr)[(size_t)A->sell_nslices];
   A->sell_on = 1; A->sell_built = 1;
+  /* x staging plan: sort the diagonals, cut into clusters no wider than SELL_CL_SPAN, one LDS segment of SELL_H + width per cluster */
+  std::vector<int32_t> scl, sldsoff(SELL_MAX_OFFS, 0);
+  {
+    std::vector<int> order(soffs.size());
+    for (size_t q = 0; q < order.size(); q++) order[q] = (int)q;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return soffs[(size_t)a] < soffs[(size_t)b]; });
+    int total = 0;
+    size_t q = 0;
+    while (q < order.size()) {
+      const int32_t first = soffs[(size_t)order[q]];
+      size_t        e = q;
+      while (e + 1 < order.size() && (int64_t)soffs[(size_t)order[e + 1]] - first <= SELL_CL_SPAN) e++;
+      const int32_t width = soffs[(size_t)order[e]] - first;
+      const int     len = SELL_H + width;
+      for (size_t k = q; k <= e; k++) sldsoff[(size_t)order[k]] = total + (soffs[(size_t)order[k]] - first);
+      scl.push_back(first); scl.push_back(total); scl.push_back(len);
+      total += (len + 1) & ~1;
+      q = e + 1;
+    }
+    A->stage_ncl = (int)(scl.size() / 3);
+    A->stage_lds_doubles = total;
+    A->stage_ok = A->stage_ncl <= SELL_CL_MAX && (size_t)total * sizeof(double) <= SELL_STAGE_MAX_BYTES;
+  }
   if (A->ctx->device < 0) return 0;
   hipStream_t st = A->ctx->stream;
   PHIP_CHECK_HIP(hipMalloc((void **)&A->d_sval, sizeof(double) * sval.size()));
@@ -446,6 +494,10 @@ static int setup_sell(phip_mat A, const int32_t *h_j, const double *h_a)
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_slen, slen.data(), slen.size(), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_sptr, A->h_sptr->data(), sizeof(int64_t) * A->h_sptr->size(), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_soffs, soffs.data(), sizeof(int32_t) * SELL_MAX_OFFS, hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_scl, sizeof(int32_t) * (scl.size() + 4)));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_sldsoff, sizeof(int32_t) * SELL_MAX_OFFS));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_scl, scl.data(), sizeof(int32_t) * scl.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_sldsoff, sldsoff.data(), sizeof(int32_t) * SELL_MAX_OFFS, hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipStreamSynchronize(st));
   return 0;
 }
@@ -560,12 +612,20 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
   hipStream_t st = A->ctx->stream;
   if (A->sell_on) {
     const unsigned grid = DOT ? (unsigned)(A->sell_nslices < PHIP_RED_BLOCKS ? A->sell_nslices : PHIP_RED_BLOCKS) : (unsigned)A->sell_nslices;
-    if (9 * A->sell_padded > PHIP_NT_MATRIX_BYTES)
-      hipLaunchKernelGGL((spmv_sell_kernel<true, DOT>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->m, A->sell_nslices, A->d_sptr, A->d_slen, A->d_sval, A->d_scode,
-                         A->d_soffs, A->sell_noffs, d_x, d_yin, d_yout, add, d_v, ctl);
-    else
-      hipLaunchKernelGGL((spmv_sell_kernel<false, DOT>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->m, A->sell_nslices, A->d_sptr, A->d_slen, A->d_sval, A->d_scode,
-                         A->d_soffs, A->sell_noffs, d_x, d_yin, d_yout, add, d_v, ctl);
+    const bool     nt = 9 * A->sell_padded > PHIP_NT_MATRIX_BYTES;
+    /* LDS staging of x is correct but measured SLOWER than gathering through L1/L2 (7-point 128^3: 26.9 -> 31.8 us; 27-point 160^3:
+       206 -> 220 us): the gathers are not what bounds this kernel.  Off unless PHIP_SELL_STAGE=1. */
+    static const int stage_env = getenv("PHIP_SELL_STAGE") ? atoi(getenv("PHIP_SELL_STAGE")) : 0;
+    const bool     stage = A->stage_ok && stage_env != 0;
+#define SELL_LAUNCH(NTv, STv)                                                                                                                        \
+  hipLaunchKernelGGL((spmv_sell_kernel<NTv, DOT, STv>), dim3(grid), dim3(PHIP_THREADS), (STv) ? sizeof(double) * (size_t)A->stage_lds_doubles : 0, st, A->m, \
+                     A->n, A->sell_nslices, A->d_sptr, A->d_slen, A->d_sval, A->d_scode, (STv) ? A->d_sldsoff : A->d_soffs, A->sell_noffs, A->d_scl,      \
+                     A->stage_ncl, d_x, d_yin, d_yout, add, d_v, ctl)
+    if (nt && stage) SELL_LAUNCH(true, true);
+    else if (nt) SELL_LAUNCH(true, false);
+    else if (stage) SELL_LAUNCH(false, true);
+    else SELL_LAUNCH(false, false);
+#undef SELL_LAUNCH
   } else {
     const unsigned grid = DOT ? (unsigned)(A->nblocks < PHIP_RED_BLOCKS ? (A->nblocks > 0 ? A->nblocks : 1) : PHIP_RED_BLOCKS) : (unsigned)A->nblocks;
     /* out-of-cache irregular matrices: non-temporal matrix stream (R-MAT scale 22: 546 -> 505 us); PHIP_CSR_NT=0/1 overrides */
