@@ -113,6 +113,9 @@ int phip_mat_plan_get(phip_mat A, int32_t *h_block_row /* nblocks+1 */);
 int phip_set_default_mat_format(int fmt);
 int phip_mat_set_format(phip_mat A, int fmt);
 int phip_mat_format_info(phip_mat A, int *format, int32_t *ndiagonals, int64_t *padded_entries);
+/* tuning: SELL-dict kernel gathers x from LDS-staged contiguous segments (one per cluster of nearby diagonals) instead of through
+ * L1/L2; same bits; measured slower on MI355X for 7- and 27-point stencils, hence off by default */
+int phip_mat_set_x_staging(phip_mat A, int on);
 /* tuning: threads_per_row (0 = auto), 1,2,4,...,64 */
 int phip_mat_set_threads_per_row(phip_mat A, int32_t tpr);
 

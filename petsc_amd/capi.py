@@ -42,6 +42,7 @@ SIGNATURES = [
     ("phip_mat_set_threads_per_row", C.c_int, [_vp, C.c_int32]),
     ("phip_set_default_mat_format", C.c_int, [C.c_int]),
     ("phip_mat_set_format", C.c_int, [_vp, C.c_int]),
+    ("phip_mat_set_x_staging", C.c_int, [_vp, C.c_int]),
     ("phip_mat_format_info", C.c_int, [_vp, C.POINTER(C.c_int), _pI, C.POINTER(C.c_int64)]),
     ("phip_vec_dot", C.c_int, [_vp, C.c_int32, _vp, _vp, _pD]),
     ("phip_vec_norm", C.c_int, [_vp, C.c_int32, _vp, C.c_int, _pD]),

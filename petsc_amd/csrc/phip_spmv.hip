@@ -68,7 +68,7 @@ struct phip_mat_s {
   int64_t *d_sptr;
   int32_t *d_soffs;
   /* LDS staging of x for the SELL-dict kernel: diagonals grouped into clusters of nearby offsets, one contiguous x segment per cluster */
-  int      stage_ok, stage_ncl, stage_lds_doubles;
+  int      stage_ok, stage_user, stage_ncl, stage_lds_doubles;
   int32_t *d_scl;     /* [ncl][3]: first offset of the cluster, start of its segment in LDS (doubles), segment length */
   int32_t *d_sldsoff; /* [256]: LDS index of x[row + diagonal] for local row 0, per diagonal code */
   std::vector<int64_t> *h_sptr;
@@ -616,7 +616,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     /* LDS staging of x is correct but measured SLOWER than gathering through L1/L2 (7-point 128^3: 26.9 -> 31.8 us; 27-point 160^3:
        206 -> 220 us): the gathers are not what bounds this kernel.  Off unless PHIP_SELL_STAGE=1. */
     static const int stage_env = getenv("PHIP_SELL_STAGE") ? atoi(getenv("PHIP_SELL_STAGE")) : 0;
-    const bool     stage = A->stage_ok && stage_env != 0;
+    const bool     stage = A->stage_ok && (stage_env != 0 || A->stage_user);
 #define SELL_LAUNCH(NTv, STv)                                                                                                                        \
   hipLaunchKernelGGL((spmv_sell_kernel<NTv, DOT, STv>), dim3(grid), dim3(PHIP_THREADS), (STv) ? sizeof(double) * (size_t)A->stage_lds_doubles : 0, st, A->m, \
                      A->n, A->sell_nslices, A->d_sptr, A->d_slen, A->d_sval, A->d_scode, (STv) ? A->d_sldsoff : A->d_soffs, A->sell_noffs, A->d_scl,      \
@@ -778,5 +778,14 @@ extern "C" int phip_mat_format_info(phip_mat A, int *format, int32_t *ndiagonals
   if (format) *format = A->sell_on ? 2 : 1;
   if (ndiagonals) *ndiagonals = A->sell_built ? A->sell_noffs : 0;
   if (padded_entries) *padded_entries = A->sell_built ? A->sell_padded : 0;
+  return 0;
+}
+
+/* tuning: gather x through LDS-staged segments in the SELL-dict kernel (see launch_spmv_t); fails when the layout has no staging plan */
+extern "C" int phip_mat_set_x_staging(phip_mat A, int on)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_set_x_staging: null matrix");
+  PHIP_REQUIRE(!on || (A->sell_built && A->stage_ok), PHIP_ERR_SUP, "phip_mat_set_x_staging: this matrix has no SELL-dict staging plan");
+  A->stage_user = on ? 1 : 0;
   return 0;
 }

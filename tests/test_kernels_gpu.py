@@ -36,7 +36,7 @@ def mat_format(ctx, A):
     return f.value, nd.value, pad.value
 
 
-def gpu_mult(ctx, ai, aj, aa, n, x, cprow=None, y0=None, inplace=False, tpr=0, fmt=0):
+def gpu_mult(ctx, ai, aj, aa, n, x, cprow=None, y0=None, inplace=False, tpr=0, fmt=0, stage=0):
     """fmt 1: CSR row-block kernel, 2: SELL-dict kernel (returns None when the matrix is not eligible), 0: the library's choice."""
     m = len(ai) - 1
     A = ctx.mat_create(m, n, ai, aj, aa, cprow)
@@ -48,6 +48,8 @@ def gpu_mult(ctx, ai, aj, aa, n, x, cprow=None, y0=None, inplace=False, tpr=0, f
         return None
     if fmt == 1:
         ctx.check(ctx.lib.phip_mat_set_format(A, 1))
+    if stage:
+        ctx.check(ctx.lib.phip_mat_set_x_staging(A, 1))
     dx = ctx.to_device(x)
     dy = ctx.to_device(np.full(max(m, 1), 7.25))
     if y0 is None:
@@ -122,11 +124,13 @@ def test_spmv_sell_dict_layout(ctx, orc, golden_dir):
         assert f == 2 and nd <= 27 and pad >= len(aj)
         ctx.check(ctx.lib.phip_mat_destroy(A))
         np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, fmt=2), yo)
+        np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, fmt=2, stage=1), yo)  # x gathered from LDS-staged segments
         np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, tpr=1), yo)
         y0 = rng.standard_normal(n)
         zo = orc.matmultadd(ai, aj, aa, x, y0)
         np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, y0=y0, fmt=2), zo)
         np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, y0=y0, inplace=True, fmt=2), zo)
+        np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, y0=y0, inplace=True, fmt=2, stage=1), zo)
     # rectangular, odd row count, empty rows in the middle, x containing Inf where no entry points (padding must not touch it)
     ai = np.array([0, 2, 2, 3, 5, 5], np.int32); aj = np.array([0, 1, 2, 3, 4], np.int32); aa = np.arange(1.0, 6.0)
     x = np.array([1.0, 2.0, 3.0, 4.0, 5.0, np.inf, np.nan])
