@@ -4,7 +4,7 @@
 
 struct RedCtl {
   double             *partial; /* [PHIP_MAX_MVEC][PHIP_RED_BLOCKS] */
-  unsigned int       *ticket;  /* arrival counters [33][32] (one used word per 128-byte line), zero on entry and on exit */
+  unsigned int       *ticket;  /* arrival counters [PHIP_RED_BLOCKS/32 + 1][32] (one used word per 128-byte line), zero on entry and on exit */
   double             *d_out;   /* device results, indexed like the partial rows */
   double             *h_slot;  /* pinned host slot (device address) or NULL: publish d_out[0..npub) there ... */
   unsigned long long *h_seq;   /* ... then store seq here */
@@ -66,9 +66,9 @@ __device__ __forceinline__ void reduce_tail(double (&acc)[NV], double *lds /* >=
     if (tk == gsize - 1) {
       __hip_atomic_store(&c.ticket[g * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned int ngroups = (unsigned int)((nb + 31) >> 5);
-      const unsigned int tk2 = __hip_atomic_fetch_add(&c.ticket[32 * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int tk2 = __hip_atomic_fetch_add(&c.ticket[(PHIP_RED_BLOCKS / 32) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (tk2 == ngroups - 1) {
-        __hip_atomic_store(&c.ticket[32 * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&c.ticket[(PHIP_RED_BLOCKS / 32) * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = 1;
       }
     }

@@ -51,8 +51,8 @@ extern "C" int phip_init(int device, phip_ctx *out)
   PHIP_CHECK_HIP(hipMalloc((void **)&c->d_partials, sizeof(double) * PHIP_MAX_MVEC * PHIP_RED_BLOCKS));
   PHIP_CHECK_HIP(hipMalloc((void **)&c->d_result, sizeof(double) * PHIP_MAX_MVEC));
   PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_result, sizeof(double) * PHIP_MAX_MVEC, hipHostMallocDefault));
-  PHIP_CHECK_HIP(hipMalloc((void **)&c->d_ticket, 8192));
-  PHIP_CHECK_HIP(hipMemsetAsync(c->d_ticket, 0, 8192, c->stream));
+  PHIP_CHECK_HIP(hipMalloc((void **)&c->d_ticket, 4 * 32 * (PHIP_RED_BLOCKS / 32 + 1)));
+  PHIP_CHECK_HIP(hipMemsetAsync(c->d_ticket, 0, 4 * 32 * (PHIP_RED_BLOCKS / 32 + 1), c->stream));
   PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_slot, sizeof(double) * PHIP_MAX_MVEC, hipHostMallocMapped | hipHostMallocCoherent));
   PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_seq, 64, hipHostMallocMapped | hipHostMallocCoherent));
   PHIP_CHECK_HIP(hipHostGetDevicePointer((void **)&c->h_slot_dev, c->h_slot, 0));

@@ -11,7 +11,7 @@
 // row 1 (one lane per workgroup stores sc1, drains vmcnt, adds to an agent-scope counter; the last arriver loads sc1).
 #include "phip_internal.h"
 
-#define MV_MAX 8 /* vectors fused per mdot/maxpy launch */
+#define MV_MAX 16 /* vectors fused per mdot/maxpy launch */
 
 struct MVPack {
   const double *y[MV_MAX];
@@ -372,22 +372,22 @@ static int reduce_launch(phip_ctx c, int kind, int32_t n, const double *d_x, int
   if (kind == 0) {
     PHIP_REQUIRE(nv >= 0 && nv <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_reduce_local: nv=%d (max %d)", nv, PHIP_MAX_MVEC);
     PHIP_REQUIRE(h_dy || !nv, PHIP_ERR_ARG_NULL, "phip_vec_reduce_local: null vector list");
-    for (int k0 = 0; k0 < nv; k0 += MV_MAX) {
-      const int g = (nv - k0 < MV_MAX) ? nv - k0 : MV_MAX;
+    /* balanced groups of at most MV_MAX vectors: x is read once per group */
+    const int ngroups = (nv + MV_MAX - 1) / MV_MAX;
+    for (int gi = 0, k0 = 0; gi < ngroups; gi++) {
+      const int g = (nv - k0 + (ngroups - gi) - 1) / (ngroups - gi);
       MVPack    P;
       for (int k = 0; k < MV_MAX; k++) { P.y[k] = (k < g) ? h_dy[k0 + k] : d_x; P.a[k] = 0.0; }
       ctl.kofs = k0;
       if (publish && k0 + g == nv) { ctl.h_slot = c->h_slot_dev; ctl.h_seq = c->h_seq_dev; ctl.seq = ++c->seq; ctl.npub = nv; *seq_out = ctl.seq; }
       switch (g) {
-      case 1: launch_mdot<1>(c, n, d_x, P, ctl, grid); break;
-      case 2: launch_mdot<2>(c, n, d_x, P, ctl, grid); break;
-      case 3: launch_mdot<3>(c, n, d_x, P, ctl, grid); break;
-      case 4: launch_mdot<4>(c, n, d_x, P, ctl, grid); break;
-      case 5: launch_mdot<5>(c, n, d_x, P, ctl, grid); break;
-      case 6: launch_mdot<6>(c, n, d_x, P, ctl, grid); break;
-      case 7: launch_mdot<7>(c, n, d_x, P, ctl, grid); break;
-      default: launch_mdot<8>(c, n, d_x, P, ctl, grid); break;
+#define MDOT_CASE(N) case N: launch_mdot<N>(c, n, d_x, P, ctl, grid); break;
+        MDOT_CASE(1) MDOT_CASE(2) MDOT_CASE(3) MDOT_CASE(4) MDOT_CASE(5) MDOT_CASE(6) MDOT_CASE(7) MDOT_CASE(8)
+        MDOT_CASE(9) MDOT_CASE(10) MDOT_CASE(11) MDOT_CASE(12) MDOT_CASE(13) MDOT_CASE(14) MDOT_CASE(15)
+#undef MDOT_CASE
+      default: launch_mdot<16>(c, n, d_x, P, ctl, grid); break;
       }
+      k0 += g;
       PHIP_CHECK_HIP(hipGetLastError());
     }
     return 0;
@@ -474,20 +474,19 @@ extern "C" int phip_vec_maxpy(phip_ctx c, int32_t n, double *d_x, int32_t nv, co
   PHIP_REQUIRE(nv >= 0, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_maxpy: nv=%d", nv);
   PHIP_REQUIRE((h_alpha && h_dy) || !nv, PHIP_ERR_ARG_NULL, "phip_vec_maxpy: null argument");
   if (!n) return 0;
-  for (int k0 = 0; k0 < nv; k0 += MV_MAX) {
-    const int g = (nv - k0 < MV_MAX) ? nv - k0 : MV_MAX;
+  const int ngroups = (nv + MV_MAX - 1) / MV_MAX; /* balanced groups: x is read and written once per group */
+  for (int gi = 0, k0 = 0; gi < ngroups; gi++) {
+    const int g = (nv - k0 + (ngroups - gi) - 1) / (ngroups - gi);
     MVPack    P;
     for (int k = 0; k < MV_MAX; k++) { P.y[k] = (k < g) ? h_dy[k0 + k] : d_x; P.a[k] = (k < g) ? h_alpha[k0 + k] : 0.0; }
     switch (g) {
-    case 1: launch_maxpy<1>(c, n, d_x, P); break;
-    case 2: launch_maxpy<2>(c, n, d_x, P); break;
-    case 3: launch_maxpy<3>(c, n, d_x, P); break;
-    case 4: launch_maxpy<4>(c, n, d_x, P); break;
-    case 5: launch_maxpy<5>(c, n, d_x, P); break;
-    case 6: launch_maxpy<6>(c, n, d_x, P); break;
-    case 7: launch_maxpy<7>(c, n, d_x, P); break;
-    default: launch_maxpy<8>(c, n, d_x, P); break;
+#define MAXPY_CASE(N) case N: launch_maxpy<N>(c, n, d_x, P); break;
+      MAXPY_CASE(1) MAXPY_CASE(2) MAXPY_CASE(3) MAXPY_CASE(4) MAXPY_CASE(5) MAXPY_CASE(6) MAXPY_CASE(7) MAXPY_CASE(8)
+      MAXPY_CASE(9) MAXPY_CASE(10) MAXPY_CASE(11) MAXPY_CASE(12) MAXPY_CASE(13) MAXPY_CASE(14) MAXPY_CASE(15)
+#undef MAXPY_CASE
+    default: launch_maxpy<16>(c, n, d_x, P); break;
     }
+    k0 += g;
     PHIP_CHECK_HIP(hipGetLastError());
   }
   return 0;
