@@ -13,7 +13,7 @@ Default workload = BASELINE.json configs[1]: 3-D 7-point Laplacian 128^3 per GPU
 value   = whole-job algorithmic HBM bytes of the K iterations / wall time (GB/s): per rank and iteration
           SpMV 12 nz + 20 m + 4 (+ the off-diagonal block's MultAdd 12 nzB + 28 mB on N > 1) + 136 m of vector kernels
           (SURVEY.md 8d).  iterations/s and the SpMV-only figures ride along in the same JSON line.
-roofline = the SpMV kernel (spmv_rowblock_kernel): 200 launches back to back between two hipEvents on the library's compute
+roofline = the SpMV kernel (spmv_sell_kernel for stencil matrices, else spmv_rowblock_kernel): 200 launches back to back between two hipEvents on the library's compute
           stream.  (Each launch inside the timed CG region is also bracketed by an event pair, phip_profile_*; that figure
           carries ~3 us of event overhead per launch and is reported beside it, not as the roofline.)
 cpu_baseline = the oracle (C restatement of the reference loops, -O3 -march=native, ONE core = MATSEQAIJ) on the same matrix,
