@@ -101,6 +101,15 @@ int phip_mat_mult(phip_mat A, const double *d_x, double *d_y);
 /* z = y + A x.  MatMultAdd_SeqAIJ, aij.c:1440-1499; d_z may alias d_y (mpiaij.c:996 calls it that way). */
 int phip_mat_multadd(phip_mat A, const double *d_x, const double *d_y, double *d_z);
 /* v[i] = a[k] where j[k]==i, else 0.  MatGetDiagonal_SeqAIJ, aij.c:1169-1202. */
+/* y = A^T x (MatMultTranspose_SeqAIJ aij.c:1258-1266) and z = y + A^T x (MatMultTransposeAdd_SeqAIJ aij.c:1207-1254; z may be y).
+ * phip_mat_transpose_setup builds the operator from the host CSR the matrix was created from (full row pointer, also for a
+ * compressed-row matrix): a second device copy holding A^T row by row, whose k-ascending row sums add the products of a column of A
+ * in ascending row order -- the order of the reference's scatter-add loop (aij.c:1238-1248) -- with no atomics: the reference's bits
+ * in the layouts that sum a row in one lane (SELL-dict; CSR with one lane per row), within 1e-12 otherwise, as for the forward product.
+ * phip_mat_update_values refreshes that copy too.  The products fail with PHIP_ERR_ARG_WRONGSTATE before the set-up call. */
+int phip_mat_transpose_setup(phip_mat A, const int32_t *h_i, const int32_t *h_j, const double *h_a);
+int phip_mat_mult_transpose(phip_mat A, const double *d_x /* m */, double *d_y /* n */);
+int phip_mat_mult_transpose_add(phip_mat A, const double *d_x /* m */, const double *d_y /* n */, double *d_z /* n */);
 int phip_mat_getdiagonal(phip_mat A, double *d_v);
 /* Row-block plan introspection (tests): number of blocks, nnz capacity per block, threads per row used. */
 int phip_mat_plan_info(phip_mat A, int32_t *nblocks, int32_t *block_nnz_cap, int32_t *threads_per_row, int64_t *nnz);
@@ -202,6 +211,13 @@ int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_procs, cons
 int phip_halo_destroy(phip_halo halo);
 int phip_halo_begin(phip_halo halo, const double *d_x_local, double *d_lvec);
 int phip_halo_end(phip_halo halo);
+/* The same plan run backwards with ADD_VALUES (VecScatterBegin/End(Mvctx, lvec, y, ADD_VALUES, SCATTER_REVERSE) of
+ * MatMultTranspose_MPIAIJ, mpiaij.c:1041-1046, and MatMultTransposeAdd_MPIAIJ :1111-1115): begin sends every segment of lvec back to
+ * the rank that owns those entries; end adds what arrived into y[to.indices] (UnPack_1 with ADD_VALUES, vpscat.c:512-515), the
+ * contributions to one entry in ascending neighbour rank (the reference: arrival order).  Nothing is added to y before end, as
+ * mpiaij.c:1044-1045 requires, so the diagonal block's transposed product may run in between. */
+int phip_halo_reverse_begin(phip_halo halo, const double *d_lvec);
+int phip_halo_reverse_end(phip_halo halo, double *d_y);
 
 #ifdef __cplusplus
 }

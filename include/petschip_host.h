@@ -143,6 +143,8 @@ PetscErrorCode MatGetOwnershipRange(Mat A, PetscInt *rstart, PetscInt *rend);
 PetscErrorCode MatCreateVecs(Mat A, Vec *right, Vec *left);
 PetscErrorCode MatMult(Mat A, Vec x, Vec y);
 PetscErrorCode MatMultAdd(Mat A, Vec x, Vec y, Vec z);
+PetscErrorCode MatMultTranspose(Mat A, Vec x, Vec y);            /* matrix.c:2259; aij.c:1258, mpiaij.c:1029 */
+PetscErrorCode MatMultTransposeAdd(Mat A, Vec x, Vec y, Vec z);  /* matrix.c:2435; aij.c:1207, mpiaij.c:1102 */
 PetscErrorCode MatGetDiagonal(Mat A, Vec v);
 PetscErrorCode MatGetRowMaxAbs(Mat A, Vec v, PetscInt idx[]);
 PetscErrorCode MatGetRowSum(Mat A, Vec v);

@@ -153,6 +153,22 @@ class Oracle:
             self.lib.orc_matmultadd_seqaij(C.c_int32(m), _ip(ai), _ip(aj), _dp(aa), C.c_int(0), C.c_int32(0), None, None, _dp(x), _dp(y), _dp(z))
         return z
 
+    def matmulttranspose(self, ai, aj, aa, n, x, y=None, cprow=None):
+        """A^T x, or y + A^T x when y is given (n = number of columns)."""
+        ai, aj, aa, x = _i32(ai), _i32(aj), _f64(aa), _f64(x)
+        m = len(ai) - 1
+        z = np.empty(n)
+        cp = (C.c_int(0), C.c_int32(0), None, None)
+        if cprow is not None:
+            ci, cr = _i32(cprow[0]), _i32(cprow[1])
+            cp = (C.c_int(1), C.c_int32(len(cr)), _ip(ci), _ip(cr))
+        if y is None:
+            self.lib.orc_matmulttranspose_seqaij(C.c_int32(m), C.c_int32(n), _ip(ai), _ip(aj), _dp(aa), *cp, _dp(x), _dp(z))
+        else:
+            y = _f64(y)
+            self.lib.orc_matmulttransposeadd_seqaij(C.c_int32(m), C.c_int32(n), _ip(ai), _ip(aj), _dp(aa), *cp, _dp(x), _dp(y), _dp(z))
+        return z
+
     def getdiagonal(self, ai, aj, aa):
         ai, aj, aa = _i32(ai), _i32(aj), _f64(aa)
         n = len(ai) - 1
@@ -317,6 +333,13 @@ class OracleOperator:
         y = np.empty(self.N)
         self.orc.lib.orc_operator_mult(self.h, _dp(x), _dp(y))
         return y
+
+    def mult_transpose(self, x, y=None):
+        x = _f64(x)
+        z = np.empty(self.N)
+        yy = _f64(y) if y is not None else z
+        self.orc.lib.orc_operator_mult_transpose(self.h, _dp(x), _dp(yy), _dp(z), C.c_int(0 if y is None else 1))
+        return z
 
     def diagonal(self):
         d = np.empty(self.N)

@@ -295,6 +295,36 @@ ORC_EXPORT void orc_matmultadd_seqaij(OInt m, const OInt *ai, const OInt *aj, co
   }
 }
 
+/* MatMultTransposeAdd_SeqAIJ, aij.c:1207-1254: y = z when distinct (:1224), then for every (compressed) row i
+   alpha = x[i]; y[idx[j]] += alpha*v[j] (:1238-1248).  n = number of columns.                    */
+ORC_EXPORT void orc_matmulttransposeadd_seqaij(OInt m, OInt n, const OInt *ai, const OInt *aj, const double *aa,
+                                               int usecprow, OInt cprow_nrows, const OInt *cprow_i, const OInt *cprow_rindex,
+                                               const double *x, const double *zz, double *yy)
+{
+  OInt i, j, nn;
+  const OInt *ii = usecprow ? cprow_i : ai;
+  double alpha;
+  if (zz != yy) memcpy(yy, zz, (size_t)n * sizeof(double));
+  if (usecprow) m = cprow_nrows;
+  for (i = 0; i < m; i++) {
+    const OInt   *idx = aj + ii[i];
+    const double *v = aa + ii[i];
+    nn = ii[i + 1] - ii[i];
+    alpha = usecprow ? x[cprow_rindex[i]] : x[i];
+    for (j = 0; j < nn; j++) yy[idx[j]] += alpha * v[j];
+  }
+}
+
+/* MatMultTranspose_SeqAIJ, aij.c:1258-1266: VecSet(yy,0.0) then the Add routine with zz == yy. */
+ORC_EXPORT void orc_matmulttranspose_seqaij(OInt m, OInt n, const OInt *ai, const OInt *aj, const double *aa,
+                                            int usecprow, OInt cprow_nrows, const OInt *cprow_i, const OInt *cprow_rindex,
+                                            const double *x, double *y)
+{
+  OInt i;
+  for (i = 0; i < n; i++) y[i] = 0.0;
+  orc_matmulttransposeadd_seqaij(m, n, ai, aj, aa, usecprow, cprow_nrows, cprow_i, cprow_rindex, x, y, y);
+}
+
 /* MatGetDiagonal_SeqAIJ, aij.c:1169-1202 (non-factored branch): first aj[j]==i, else 0. */
 ORC_EXPORT void orc_getdiagonal_seqaij(OInt n, const OInt *ai, const OInt *aj, const double *aa, double *x)
 {
@@ -713,6 +743,25 @@ ORC_EXPORT void orc_operator_mult(OrcOperator *op, const double *x, double *y)
     orc_matmult_seqaij(m, op->Ai[r], op->Aj[r], op->Aa[r], 0, 0, NULL, NULL, x + rs, y + rs);  /* A->mult */
     orc_matmultadd_seqaij(m, op->Bi[r], op->Bj[r], op->Ba[r], op->Bcp_use[r], op->Bcp_n[r], op->Bcp_i[r], op->Bcp_r[r],
                           op->lvec, y + rs, y + rs);                              /* B->multadd(lvec,y,y) */
+  }
+}
+
+/* MatMultTranspose_MPIAIJ, mpiaij.c:1029-1056 / MatMultTransposeAdd_MPIAIJ :1102-1117 (add != 0: z = y + A^T x):
+   lvec_r = B_r^T x_r; z_r = (y_r +) A_r^T x_r; reverse scatter with ADD_VALUES: z[garray_r[k]] += lvec_r[k].
+   The reference adds the messages in arrival order; this emulation adds them in ascending sender rank. */
+ORC_EXPORT void orc_operator_mult_transpose(OrcOperator *op, const double *x, const double *y, double *z, int add)
+{
+  OInt r, k;
+  for (r = 0; r < op->size; r++) {
+    OInt rs = op->range[r], m = op->range[r + 1] - rs;
+    if (add) orc_matmulttransposeadd_seqaij(m, m, op->Ai[r], op->Aj[r], op->Aa[r], 0, 0, NULL, NULL, x + rs, y + rs, z + rs);
+    else     orc_matmulttranspose_seqaij(m, m, op->Ai[r], op->Aj[r], op->Aa[r], 0, 0, NULL, NULL, x + rs, z + rs);
+  }
+  for (r = 0; r < op->size; r++) {
+    OInt rs = op->range[r], m = op->range[r + 1] - rs;
+    orc_matmulttranspose_seqaij(m, op->ec[r], op->Bi[r], op->Bj[r], op->Ba[r], op->Bcp_use[r], op->Bcp_n[r], op->Bcp_i[r], op->Bcp_r[r],
+                                x + rs, op->lvec);
+    for (k = 0; k < op->ec[r]; k++) z[op->garray[r][k]] += op->lvec[k];
   }
 }
 

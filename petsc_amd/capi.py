@@ -36,6 +36,9 @@ SIGNATURES = [
     ("phip_mat_destroy", C.c_int, [_vp]),
     ("phip_mat_mult", C.c_int, [_vp, _vp, _vp]),
     ("phip_mat_multadd", C.c_int, [_vp, _vp, _vp, _vp]),
+    ("phip_mat_transpose_setup", C.c_int, [_vp, _pI, _pI, _pD]),
+    ("phip_mat_mult_transpose", C.c_int, [_vp, _vp, _vp]),
+    ("phip_mat_mult_transpose_add", C.c_int, [_vp, _vp, _vp, _vp]),
     ("phip_mat_getdiagonal", C.c_int, [_vp, _vp]),
     ("phip_mat_plan_info", C.c_int, [_vp, _pI, _pI, _pI, C.POINTER(C.c_int64)]),
     ("phip_mat_plan_get", C.c_int, [_vp, _pI]),
@@ -81,6 +84,8 @@ SIGNATURES = [
     ("phip_halo_destroy", C.c_int, [_vp]),
     ("phip_halo_begin", C.c_int, [_vp, _vp, _vp]),
     ("phip_halo_end", C.c_int, [_vp]),
+    ("phip_halo_reverse_begin", C.c_int, [_vp, _vp]),
+    ("phip_halo_reverse_end", C.c_int, [_vp, _vp]),
 ]
 
 

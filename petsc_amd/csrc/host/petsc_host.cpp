@@ -786,6 +786,7 @@ struct HostAIJ {
   PetscInt nz = 0, nonzerorowcnt = 0, rmax = 0;
   bool     cprow_use = false;
   phip_mat dev = NULL;
+  bool     t_ready = false;        /* the device matrix carries its transposed copy (phip_mat_transpose_setup) */
 
   void prealloc(PetscInt m_, PetscInt n_, PetscInt nzrow, const PetscInt *nnz)
   {
@@ -907,6 +908,7 @@ struct HostAIJ {
       if (values_dirty) CHKPHIP(phip_mat_update_values(dev, a.data()));
     } else {
       if (dev) { CHKPHIP(phip_mat_destroy(dev)); dev = NULL; }
+      t_ready = false;
       CHKPHIP(phip_mat_create(ctx, m, n, ai.data(), j.data(), a.data(), cprow_use ? 1 : 0, (PetscInt)cprow_rindex.size(),
                               cprow_use ? cprow_i.data() : NULL, cprow_use ? cprow_rindex.data() : NULL, &dev));
       dev_nonzerostate = nonzerostate;
@@ -914,7 +916,15 @@ struct HostAIJ {
     values_dirty = false;
     return 0;
   }
-  void destroy() { if (dev) phip_mat_destroy(dev); dev = NULL; }
+  /* built at the first transposed product; phip_mat_update_values keeps it current while the nonzero pattern stays */
+  PetscErrorCode need_transpose()
+  {
+    if (t_ready) return 0;
+    CHKPHIP(phip_mat_transpose_setup(dev, ai.data(), j.data(), a.data()));
+    t_ready = true;
+    return 0;
+  }
+  void destroy() { if (dev) phip_mat_destroy(dev); dev = NULL; t_ready = false; }
 };
 
 /* ================================================================================================ */
@@ -923,6 +933,8 @@ struct _MatOps { /* the _MatOps slots (include/petsc/private/matimpl.h:28-206) t
   PetscErrorCode (*setvalues)(Mat, PetscInt, const PetscInt[], PetscInt, const PetscInt[], const PetscScalar[], InsertMode);
   PetscErrorCode (*mult)(Mat, Vec, Vec);
   PetscErrorCode (*multadd)(Mat, Vec, Vec, Vec);
+  PetscErrorCode (*multtranspose)(Mat, Vec, Vec);
+  PetscErrorCode (*multtransposeadd)(Mat, Vec, Vec, Vec);
   PetscErrorCode (*getdiagonal)(Mat, Vec);
   PetscErrorCode (*assemblyend)(Mat, MatAssemblyType);
   PetscErrorCode (*zeroentries)(Mat);
@@ -1030,6 +1042,19 @@ static PetscErrorCode MatMult_SeqAIJHIP(Mat A, Vec x, Vec y)
   return 0;
 }
 static PetscErrorCode MatMultAdd_SeqAIJHIP(Mat A, Vec x, Vec y, Vec z) { CHKPHIP(phip_mat_multadd(A->A.dev, x->d, y->d, z->d)); return 0; }
+/* MatMultTranspose_SeqAIJ aij.c:1258-1266 / MatMultTransposeAdd_SeqAIJ aij.c:1207-1254 */
+static PetscErrorCode MatMultTranspose_SeqAIJHIP(Mat A, Vec x, Vec y)
+{
+  PetscErrorCode ierr = A->A.need_transpose(); CHKERRQ(ierr);
+  CHKPHIP(phip_mat_mult_transpose(A->A.dev, x->d, y->d));
+  return 0;
+}
+static PetscErrorCode MatMultTransposeAdd_SeqAIJHIP(Mat A, Vec x, Vec y, Vec z)
+{
+  PetscErrorCode ierr = A->A.need_transpose(); CHKERRQ(ierr);
+  CHKPHIP(phip_mat_mult_transpose_add(A->A.dev, x->d, y->d, z->d));
+  return 0;
+}
 static PetscErrorCode MatGetDiagonal_SeqAIJHIP(Mat A, Vec v) { CHKPHIP(phip_mat_getdiagonal(A->A.dev, v->d)); return 0; }
 static PetscErrorCode MatZeroEntries_AIJHIP(Mat A)
 {
@@ -1066,6 +1091,7 @@ static PetscErrorCode MatCreate_SeqAIJHIP(Mat A)
   if (A->comm->size > 1) SETERRQ(PETSC_ERR_ARG_WRONG, "Comm must be of size 1"); /* aij.c:3937 */
   PetscErrorCode ierr = mat_layouts(A); CHKERRQ(ierr);
   A->ops.setvalues = MatSetValues_SeqAIJHIP; A->ops.mult = MatMult_SeqAIJHIP; A->ops.multadd = MatMultAdd_SeqAIJHIP;
+  A->ops.multtranspose = MatMultTranspose_SeqAIJHIP; A->ops.multtransposeadd = MatMultTransposeAdd_SeqAIJHIP;
   A->ops.getdiagonal = MatGetDiagonal_SeqAIJHIP; A->ops.assemblyend = MatAssemblyEnd_SeqAIJHIP; A->ops.zeroentries = MatZeroEntries_AIJHIP;
   A->ops.getvecs = MatCreateVecs_AIJHIP; A->ops.destroy = MatDestroy_AIJHIP;
   A->type = MATSEQAIJHIP; A->type_set = true; A->mpi = false;
@@ -1249,6 +1275,29 @@ static PetscErrorCode MatMultAdd_MPIAIJHIP(Mat A, Vec x, Vec y, Vec z)
   CHKPHIP(phip_mat_multadd(A->B.dev, A->lvec, z->d, z->d));
   return 0;
 }
+/* MatMultTranspose_MPIAIJ mpiaij.c:1029-1056 (the !merged branch): lvec = B^T x; reverse scatter begins; y = A^T x; the scatter's end
+   adds the ghost contributions into y.  The exchange overlaps the diagonal block's transposed product. */
+static PetscErrorCode MatMultTranspose_MPIAIJHIP(Mat A, Vec x, Vec y)
+{
+  PetscErrorCode ierr = A->A.need_transpose(); CHKERRQ(ierr);
+  ierr = A->B.need_transpose(); CHKERRQ(ierr);
+  CHKPHIP(phip_mat_mult_transpose(A->B.dev, x->d, A->lvec));
+  CHKPHIP(phip_halo_reverse_begin(A->halo, A->lvec));
+  CHKPHIP(phip_mat_mult_transpose(A->A.dev, x->d, y->d));
+  CHKPHIP(phip_halo_reverse_end(A->halo, y->d));
+  return 0;
+}
+/* MatMultTransposeAdd_MPIAIJ mpiaij.c:1102-1117 */
+static PetscErrorCode MatMultTransposeAdd_MPIAIJHIP(Mat A, Vec x, Vec y, Vec z)
+{
+  PetscErrorCode ierr = A->A.need_transpose(); CHKERRQ(ierr);
+  ierr = A->B.need_transpose(); CHKERRQ(ierr);
+  CHKPHIP(phip_mat_mult_transpose(A->B.dev, x->d, A->lvec));
+  CHKPHIP(phip_halo_reverse_begin(A->halo, A->lvec));
+  CHKPHIP(phip_mat_mult_transpose_add(A->A.dev, x->d, y->d, z->d));
+  CHKPHIP(phip_halo_reverse_end(A->halo, z->d));
+  return 0;
+}
 /* MatGetDiagonal_MPIAIJ mpiaij.c:1125-1135 */
 static PetscErrorCode MatGetDiagonal_MPIAIJHIP(Mat A, Vec v)
 {
@@ -1262,6 +1311,7 @@ static PetscErrorCode MatCreate_MPIAIJHIP(Mat A)
 {
   PetscErrorCode ierr = mat_layouts(A); CHKERRQ(ierr);
   A->ops.setvalues = MatSetValues_MPIAIJHIP; A->ops.mult = MatMult_MPIAIJHIP; A->ops.multadd = MatMultAdd_MPIAIJHIP;
+  A->ops.multtranspose = MatMultTranspose_MPIAIJHIP; A->ops.multtransposeadd = MatMultTransposeAdd_MPIAIJHIP;
   A->ops.getdiagonal = MatGetDiagonal_MPIAIJHIP; A->ops.assemblyend = MatAssemblyEnd_MPIAIJHIP; A->ops.zeroentries = MatZeroEntries_AIJHIP;
   A->ops.getvecs = MatCreateVecs_AIJHIP; A->ops.destroy = MatDestroy_AIJHIP;
   A->type = MATMPIAIJHIP; A->type_set = true; A->mpi = true;
@@ -1467,6 +1517,32 @@ extern "C" PetscErrorCode MatMultAdd(Mat A, Vec v1, Vec v2, Vec v3) /* matrix.c:
   if (A->m != v2->n) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec v2: local dim %d %d", A->m, v2->n);
   if (v1 == v3) SETERRQ(PETSC_ERR_ARG_IDN, "v1 and v3 must be different vectors");
   PetscErrorCode ierr = (*A->ops.multadd)(A, v1, v2, v3); CHKERRQ(ierr);
+  v3->state++;
+  return 0;
+}
+extern "C" PetscErrorCode MatMultTranspose(Mat A, Vec x, Vec y) /* matrix.c:2259-2288 */
+{
+  MatCheckAssembled(A, "MatMultTranspose"); VecCheckReady(x, "MatMultTranspose"); VecCheckReady(y, "MatMultTranspose");
+  if (x == y) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "x and y must be different vectors");
+  if (A->M != x->N) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec x: global dim %d %d", A->M, x->N);
+  if (A->N != y->N) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec y: global dim %d %d", A->N, y->N);
+  if (A->m != x->n) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec x: local dim %d %d", A->m, x->n);
+  if (A->n != y->n) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec y: local dim %d %d", A->n, y->n);
+  if (!A->ops.multtranspose) SETERRQ(PETSC_ERR_SUP, "This matrix type does not have a multiply tranpose defined");
+  PetscErrorCode ierr = (*A->ops.multtranspose)(A, x, y); CHKERRQ(ierr);
+  y->state++;
+  return 0;
+}
+extern "C" PetscErrorCode MatMultTransposeAdd(Mat A, Vec v1, Vec v2, Vec v3) /* matrix.c:2435-2462 */
+{
+  MatCheckAssembled(A, "MatMultTransposeAdd"); VecCheckReady(v1, "MatMultTransposeAdd"); VecCheckReady(v2, "MatMultTransposeAdd"); VecCheckReady(v3, "MatMultTransposeAdd");
+  if (!A->ops.multtransposeadd) SETERRQ(PETSC_ERR_SUP, "Mat type %s", A->type.c_str());
+  if (v1 == v3) SETERRQ(PETSC_ERR_ARG_IDN, "v1 and v3 must be different vectors");
+  if (A->M != v1->N) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec v1: global dim %d %d", A->M, v1->N);
+  if (A->N != v2->N) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec v2: global dim %d %d", A->N, v2->N);
+  if (A->N != v3->N) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec v3: global dim %d %d", A->N, v3->N);
+  if (A->m != v1->n || A->n != v2->n || A->n != v3->n) SETERRQ(PETSC_ERR_ARG_SIZ, "Mat mat,Vec v1,v2,v3: local dims %d %d, %d %d %d", A->m, A->n, v1->n, v2->n, v3->n);
+  PetscErrorCode ierr = (*A->ops.multtransposeadd)(A, v1, v2, v3); CHKERRQ(ierr);
   v3->state++;
   return 0;
 }

@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -112,6 +113,11 @@ struct phip_halo_s {
   hipEvent_t ev_packed, ev_done;
   const double *cur_lvec;
   double   *lvec;
+  /* reverse exchange with ADD_VALUES: the distinct local targets of to_indices, and for each the positions in the receive buffer that add
+     into it (ascending = ascending neighbour rank) */
+  int32_t   ntgt;
+  int32_t  *d_tgt, *d_tptr, *d_tpos;
+  const double *rev_lvec;
 };
 
 extern "C" int phip_comm_unique_id(void *id128)
@@ -349,11 +355,33 @@ extern "C" int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_
   for (int i = 0; i < h->nsend; i++) PHIP_REQUIRE(to_indices[i] >= 0, PHIP_ERR_ARG_OUTOFRANGE, "phip_halo_create: negative send index");
   phip_ctx ctx = comm->ctx;
   h->d_to_indices = NULL; h->d_sendbuf = NULL; h->lvec = NULL;
+  h->ntgt = 0; h->d_tgt = h->d_tptr = h->d_tpos = NULL; h->rev_lvec = NULL;
   if (ctx->device < 0) { *out = h; return 0; } /* planning-only: the plan stays on the host */
   PHIP_CHECK_HIP(hipSetDevice(ctx->device));
   PHIP_CHECK_HIP(hipMalloc((void **)&h->d_to_indices, sizeof(int32_t) * ((size_t)h->nsend + 4)));
   PHIP_CHECK_HIP(hipMalloc((void **)&h->d_sendbuf, sizeof(double) * ((size_t)h->nsend + 2)));
   if (h->nsend) PHIP_CHECK_HIP(hipMemcpyAsync(h->d_to_indices, to_indices, sizeof(int32_t) * (size_t)h->nsend, hipMemcpyHostToDevice, ctx->stream));
+  {
+    std::vector<std::pair<int32_t, int32_t>> byt((size_t)h->nsend);
+    for (int32_t k = 0; k < h->nsend; k++) byt[(size_t)k] = std::make_pair(to_indices[k], k);
+    std::sort(byt.begin(), byt.end());
+    std::vector<int32_t> tgt, tptr(1, 0), tpos((size_t)h->nsend + 1);
+    for (int32_t k = 0; k < h->nsend; k++) {
+      if (!k || byt[(size_t)k].first != byt[(size_t)k - 1].first) { if (k) tptr.push_back(k); tgt.push_back(byt[(size_t)k].first); }
+      tpos[(size_t)k] = byt[(size_t)k].second;
+    }
+    if (h->nsend) tptr.push_back(h->nsend);
+    h->ntgt = (int32_t)tgt.size();
+    PHIP_CHECK_HIP(hipMalloc((void **)&h->d_tgt, sizeof(int32_t) * ((size_t)h->ntgt + 4)));
+    PHIP_CHECK_HIP(hipMalloc((void **)&h->d_tptr, sizeof(int32_t) * ((size_t)h->ntgt + 4)));
+    PHIP_CHECK_HIP(hipMalloc((void **)&h->d_tpos, sizeof(int32_t) * ((size_t)h->nsend + 4)));
+    if (h->nsend) {
+      PHIP_CHECK_HIP(hipMemcpyAsync(h->d_tgt, tgt.data(), sizeof(int32_t) * (size_t)h->ntgt, hipMemcpyHostToDevice, ctx->stream));
+      PHIP_CHECK_HIP(hipMemcpyAsync(h->d_tptr, tptr.data(), sizeof(int32_t) * ((size_t)h->ntgt + 1), hipMemcpyHostToDevice, ctx->stream));
+      PHIP_CHECK_HIP(hipMemcpyAsync(h->d_tpos, tpos.data(), sizeof(int32_t) * (size_t)h->nsend, hipMemcpyHostToDevice, ctx->stream));
+    }
+    PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream)); /* the staging vectors go out of scope here */
+  }
   PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   PHIP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
   PHIP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
@@ -368,7 +396,7 @@ extern "C" int phip_halo_destroy(phip_halo h)
   hipSetDevice(h->comm->ctx->device);
   hipStreamSynchronize(h->comm->ctx->stream);
   hipStreamSynchronize(h->comm->ctx->comm_stream);
-  hipFree(h->d_to_indices); hipFree(h->d_sendbuf);
+  hipFree(h->d_to_indices); hipFree(h->d_sendbuf); hipFree(h->d_tgt); hipFree(h->d_tptr); hipFree(h->d_tpos);
   hipEventDestroy(h->ev_packed); hipEventDestroy(h->ev_done);
   delete h;
   return 0;
@@ -436,5 +464,85 @@ extern "C" int phip_halo_end(phip_halo h)
   }
   PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   g->barrier();
+  return 0;
+}
+
+/* ---- reverse ghost exchange with ADD_VALUES (the scatter of MatMultTranspose_MPIAIJ, mpiaij.c:1041-1046, 1111-1115) ------------------
+   The roles swap: every segment of lvec goes back to the rank that owns those entries (VecScatterBegin_1 with SCATTER_REVERSE,
+   vpscat.h:24-30 swaps to/from), and the owner adds what it receives into y[to.indices] (UnPack_1 with ADD_VALUES, vpscat.c:512-515).
+   The reference adds the messages in arrival order (MPI_Waitany, vpscat.h:165); here each target entry adds its contributions in
+   ascending neighbour rank, one thread per distinct target: deterministic and free of atomics. */
+__global__ __launch_bounds__(PHIP_THREADS) void halo_unpack_add_kernel(int32_t nt, const int32_t *__restrict__ tgt, const int32_t *__restrict__ tptr,
+                                                                     const int32_t *__restrict__ tpos, const double *__restrict__ buf, double *__restrict__ y)
+{
+  const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
+  for (int64_t t = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; t < nt; t += stride) {
+    double s = y[tgt[t]];
+    for (int32_t k = tptr[t]; k < tptr[t + 1]; k++) s += buf[tpos[k]];
+    y[tgt[t]] = s;
+  }
+}
+
+extern "C" int phip_halo_reverse_begin(phip_halo h, const double *d_lvec)
+{
+  PHIP_REQUIRE(h && (d_lvec || !h->nrecv), PHIP_ERR_ARG_NULL, "phip_halo_reverse_begin: null argument");
+  phip_comm c = h->comm;
+  phip_ctx  ctx = c->ctx;
+  h->rev_lvec = d_lvec;
+  if (c->size == 1) return 0;
+  PHIP_NEED_DEVICE(ctx, "phip_halo_reverse_begin");
+  PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS, PHIP_ERR_SUP, "phip_halo_reverse_begin: the callbacks backend carries set-up traffic only");
+  if (c->backend == BACKEND_RCCL) {
+    /* lvec is complete once everything queued on the compute stream so far has run; the receive buffer is the forward send buffer
+       (one scatter context carries one exchange at a time, vscat.c:1670) */
+    PHIP_CHECK_HIP(hipEventRecord(h->ev_packed, ctx->stream));
+    PHIP_CHECK_HIP(hipStreamWaitEvent(ctx->comm_stream, h->ev_packed, 0));
+    if (h->to_n || h->from_n) {
+      PHIP_CHECK_NCCL(g_rccl.GroupStart());
+      for (int i = 0; i < h->from_n; i++) {
+        const size_t cnt = (size_t)(h->from_starts[(size_t)i + 1] - h->from_starts[(size_t)i]);
+        if (cnt) PHIP_CHECK_NCCL(g_rccl.Send(d_lvec + h->from_starts[(size_t)i], cnt, ncclDouble, h->from_procs[(size_t)i], c->nccl, ctx->comm_stream));
+      }
+      for (int i = 0; i < h->to_n; i++) {
+        const size_t cnt = (size_t)(h->to_starts[(size_t)i + 1] - h->to_starts[(size_t)i]);
+        if (cnt) PHIP_CHECK_NCCL(g_rccl.Recv(h->d_sendbuf + h->to_starts[(size_t)i], cnt, ncclDouble, h->to_procs[(size_t)i], c->nccl, ctx->comm_stream));
+      }
+      PHIP_CHECK_NCCL(g_rccl.GroupEnd());
+    }
+    PHIP_CHECK_HIP(hipEventRecord(h->ev_done, ctx->comm_stream));
+    return 0;
+  }
+  /* threads: lvec must be complete before a peer copies from it in phip_halo_reverse_end */
+  PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  c->tg->slot_a[(size_t)c->rank] = h;
+  return 0;
+}
+
+extern "C" int phip_halo_reverse_end(phip_halo h, double *d_y)
+{
+  PHIP_REQUIRE(h && (d_y || !h->nsend), PHIP_ERR_ARG_NULL, "phip_halo_reverse_end: null argument");
+  phip_comm c = h->comm;
+  phip_ctx  ctx = c->ctx;
+  if (c->size == 1) return 0;
+  if (c->backend == BACKEND_RCCL) PHIP_CHECK_HIP(hipStreamWaitEvent(ctx->stream, h->ev_done, 0));
+  else {
+    ThreadGroup *g = c->tg;
+    g->barrier();
+    for (int i = 0; i < h->to_n; i++) {
+      const phip_halo_s *peer = (const phip_halo_s *)g->slot_a[(size_t)h->to_procs[(size_t)i]];
+      const int32_t      cnt = h->to_starts[(size_t)i + 1] - h->to_starts[(size_t)i];
+      int                seg = -1;
+      for (int k = 0; k < peer->from_n; k++) if (peer->from_procs[(size_t)k] == c->rank) seg = k;
+      PHIP_REQUIRE(seg >= 0 && peer->from_starts[(size_t)seg + 1] - peer->from_starts[(size_t)seg] == cnt, PHIP_ERR_ARG_SIZ,
+                   "phip_halo_reverse_end: rank %d expects %d entries back from rank %d, plan mismatch", c->rank, cnt, h->to_procs[(size_t)i]);
+      if (cnt) PHIP_CHECK_HIP(hipMemcpyAsync(h->d_sendbuf + h->to_starts[(size_t)i], peer->rev_lvec + peer->from_starts[(size_t)seg], sizeof(double) * (size_t)cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    g->barrier(); /* every rank has read its peers' lvec before anyone overwrites it */
+  }
+  if (h->ntgt) {
+    hipLaunchKernelGGL(halo_unpack_add_kernel, dim3(phip_grid_for(h->ntgt, 1, 1024)), dim3(PHIP_THREADS), 0, ctx->stream, h->ntgt, h->d_tgt, h->d_tptr, h->d_tpos, h->d_sendbuf, d_y);
+    PHIP_CHECK_HIP(hipGetLastError());
+  }
   return 0;
 }

@@ -72,6 +72,9 @@ struct phip_mat_s {
   int32_t *d_scl;     /* [ncl][3]: first offset of the cluster, start of its segment in LDS (doubles), segment length */
   int32_t *d_sldsoff; /* [256]: LDS index of x[row + diagonal] for local row 0, per diagonal code */
   std::vector<int64_t> *h_sptr;
+  /* operator of y = A^T x: a second matrix holding A^T row by row, built on request (phip_mat_transpose_setup) */
+  phip_mat              T;
+  std::vector<int32_t> *t_perm; /* entry k of A^T is entry t_perm[k] of A */
 };
 
 /* Matrix entries are read once per launch.  When the matrix is much larger than the 256 MiB Infinity Cache, non-temporal loads keep
@@ -579,6 +582,12 @@ extern "C" int phip_mat_update_values(phip_mat A, const double *h_a)
 {
   PHIP_REQUIRE(A && (h_a || !A->nnz), PHIP_ERR_ARG_NULL, "phip_mat_update_values: null argument");
   if (A->ctx->device < 0) return 0;
+  if (A->T) { /* same nonzero pattern: the transposed copy takes the new values through its permutation */
+    std::vector<double> ta((size_t)A->nnz + 1);
+    for (int64_t k = 0; k < A->nnz; k++) ta[(size_t)k] = h_a[(*A->t_perm)[(size_t)k]];
+    int rc = phip_mat_update_values(A->T, ta.data());
+    if (rc) return rc;
+  }
   PHIP_CHECK_HIP(hipSetDevice(A->ctx->device));
   if (A->nnz) PHIP_CHECK_HIP(hipMemcpyAsync(A->d_val, h_a, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice, A->ctx->stream));
   if (A->sell_built) {
@@ -595,6 +604,8 @@ extern "C" int phip_mat_update_values(phip_mat A, const double *h_a)
 extern "C" int phip_mat_destroy(phip_mat A)
 {
   if (!A) return 0;
+  if (A->T) { phip_mat_destroy(A->T); A->T = NULL; }
+  delete A->t_perm; A->t_perm = NULL;
   if (A->ctx->device < 0) { delete A->h_rowptr; delete A->h_blkrow; delete A->h_blktpr; delete A->h_sptr; delete A; return 0; }
   hipSetDevice(A->ctx->device);
   hipStreamSynchronize(A->ctx->stream);
@@ -715,6 +726,55 @@ extern "C" int phip_mat_multadd_dot(phip_mat A, const double *d_x, double *d_y, 
   return launch_spmv_dot(A, d_x, d_y, d_y, 1, d_v, ctl);
 }
 
+/* ---- transposed products ------------------------------------------------------------------------------------------------------
+   MatMultTransposeAdd_SeqAIJ (aij.c:1207-1254) walks the rows of A and adds alpha*v[j] into y[idx[j]]: entry c of the result takes the
+   products of column c in ascending row order, starting from the old y[c] (or from the 0.0 of VecSet, aij.c:1263).  Row c of the
+   explicit transpose, summed k-ascending by the ordinary product kernels, adds the same rounded products in the same order, so the
+   result has the reference's bits, needs no atomics, and streams at the speed of the forward product (A^T of a stencil matrix is a
+   stencil matrix: SELL-dict applies).  The price is a second copy of the matrix in HBM, paid only by callers of the transpose. */
+extern "C" int phip_mat_transpose_setup(phip_mat A, const int32_t *h_i, const int32_t *h_j, const double *h_a)
+{
+  PHIP_REQUIRE(A && h_i, PHIP_ERR_ARG_NULL, "phip_mat_transpose_setup: null argument");
+  PHIP_REQUIRE(h_i[0] == 0 && (int64_t)h_i[A->m] == A->nnz, PHIP_ERR_ARG_SIZ, "phip_mat_transpose_setup: the CSR passed has %d nonzeros, the matrix %lld", h_i[A->m], (long long)A->nnz);
+  PHIP_REQUIRE(!A->nnz || (h_j && h_a), PHIP_ERR_ARG_NULL, "phip_mat_transpose_setup: null j/a");
+  if (A->T) { phip_mat_destroy(A->T); A->T = NULL; }
+  delete A->t_perm;
+  A->t_perm = new std::vector<int32_t>((size_t)A->nnz + 1);
+  std::vector<int32_t> ti((size_t)A->n + 1, 0), tj((size_t)A->nnz + 1);
+  std::vector<double>  ta((size_t)A->nnz + 1);
+  for (int64_t k = 0; k < A->nnz; k++) {
+    PHIP_REQUIRE(h_j[k] >= 0 && h_j[k] < A->n, PHIP_ERR_ARG_OUTOFRANGE, "phip_mat_transpose_setup: column %d out of range at entry %lld", h_j[k], (long long)k);
+    ti[(size_t)h_j[k] + 1]++;
+  }
+  for (int32_t c = 0; c < A->n; c++) ti[(size_t)c + 1] += ti[(size_t)c];
+  std::vector<int32_t> fill(ti.begin(), ti.end() - 1);
+  for (int32_t r = 0; r < A->m; r++) /* rows ascending: a stable counting sort by column */
+    for (int32_t k = h_i[r]; k < h_i[r + 1]; k++) {
+      const int32_t q = fill[(size_t)h_j[k]]++;
+      tj[(size_t)q] = r; ta[(size_t)q] = h_a[k]; (*A->t_perm)[(size_t)q] = k;
+    }
+  int rc = phip_mat_create(A->ctx, A->n, A->m, ti.data(), tj.data(), ta.data(), 0, 0, NULL, NULL, &A->T);
+  if (rc) return rc;
+  /* the tuning choices made for A carry over */
+  if (A->tpr_user && (rc = phip_mat_set_threads_per_row(A->T, A->tpr_user))) return rc;
+  if (A->sell_built && !A->sell_on) A->T->sell_on = 0;
+  return 0;
+}
+
+extern "C" int phip_mat_mult_transpose(phip_mat A, const double *d_x, double *d_y)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_mult_transpose: null matrix");
+  PHIP_REQUIRE(A->T, PHIP_ERR_ARG_WRONGSTATE, "phip_mat_mult_transpose: call phip_mat_transpose_setup first");
+  return phip_mat_mult(A->T, d_x, d_y);
+}
+
+extern "C" int phip_mat_mult_transpose_add(phip_mat A, const double *d_x, const double *d_y, double *d_z)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_mult_transpose_add: null matrix");
+  PHIP_REQUIRE(A->T, PHIP_ERR_ARG_WRONGSTATE, "phip_mat_mult_transpose_add: call phip_mat_transpose_setup first");
+  return phip_mat_multadd(A->T, d_x, d_y, d_z);
+}
+
 extern "C" int phip_mat_getdiagonal(phip_mat A, double *d_v)
 {
   PHIP_REQUIRE(A && (d_v || !A->m), PHIP_ERR_ARG_NULL, "phip_mat_getdiagonal: null argument");
@@ -751,6 +811,7 @@ extern "C" int phip_mat_set_threads_per_row(phip_mat A, int32_t tpr)
   PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_set_threads_per_row: null matrix");
   PHIP_REQUIRE(tpr >= 0 && tpr <= 64 && (tpr & (tpr - 1)) == 0, PHIP_ERR_ARG_OUTOFRANGE, "threads per row must be 0 or a power of two <= 64, got %d", tpr);
   A->tpr_user = tpr;
+  if (A->T) { int rc = phip_mat_set_threads_per_row(A->T, tpr); if (rc) return rc; }
   return upload_plan(A);
 }
 
@@ -769,6 +830,7 @@ extern "C" int phip_mat_set_format(phip_mat A, int fmt)
   PHIP_REQUIRE(fmt >= 0 && fmt <= 2, PHIP_ERR_ARG_OUTOFRANGE, "phip_mat_set_format: %d", fmt);
   PHIP_REQUIRE(fmt != 2 || A->sell_built, PHIP_ERR_SUP, "phip_mat_set_format: no SELL-dict copy was built for this matrix");
   A->sell_on = (fmt != 1 && A->sell_built) ? 1 : 0;
+  if (A->T) A->T->sell_on = (fmt != 1 && A->T->sell_built) ? 1 : 0;
   return 0;
 }
 

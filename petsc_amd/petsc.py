@@ -404,6 +404,17 @@ class Mat:
 
     def zero_entries(self): chk(lib().MatZeroEntries(self.h))
 
+    def set_global_values(self, ai, aj, aa):
+        """INSERT this rank's rows of a global CSR (MatSetValues row by row, global columns) and assemble: with an unchanged nonzero
+        pattern only the values travel to the device (MatAssemblyEnd, aij.c:968-1024 keeps nonzerostate)."""
+        ai, aj, aa = _i32(ai), _i32(aj), _f64(aa)
+        lo, hi = self.ownership_range()
+        for r in range(lo, hi):
+            s, e = int(ai[r]), int(ai[r + 1])
+            if e > s:
+                self.set_values([r], aj[s:e], aa[s:e])
+        self.assemble()
+
     def zero_rows(self, rows, diag=0.0):
         rows = _i32(rows)
         chk(lib().MatZeroRows(self.h, len(rows), _p(rows), diag, None, None))
@@ -426,6 +437,8 @@ class Mat:
 
     def mult(self, x, y): chk(lib().MatMult(self.h, x.h, y.h))
     def mult_add(self, x, y, z): chk(lib().MatMultAdd(self.h, x.h, y.h, z.h))
+    def mult_transpose(self, x, y): chk(lib().MatMultTranspose(self.h, x.h, y.h))
+    def mult_transpose_add(self, x, y, z): chk(lib().MatMultTransposeAdd(self.h, x.h, y.h, z.h))
     def get_diagonal(self, v): chk(lib().MatGetDiagonal(self.h, v.h))
     def get_row_max_abs(self, v): chk(lib().MatGetRowMaxAbs(self.h, v.h, None))
     def get_row_sum(self, v): chk(lib().MatGetRowSum(self.h, v.h))

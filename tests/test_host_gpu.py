@@ -171,6 +171,56 @@ def test_matmult_golden(orc, golden_dir, name, size):
     np.testing.assert_array_equal(d, g["diag"])
 
 
+@pytest.mark.parametrize("name", ["small", "medium", "arco1", "poisson1", "ns-real-int32-float64"])
+@pytest.mark.parametrize("size", [1, 2, 3, 4])
+def test_matmulttranspose_golden(orc, golden_dir, name, size):
+    """MatMultTranspose / MatMultTransposeAdd on Seq and MPI matrices (aij.c:1207-1266, mpiaij.c:1029-1056, 1102-1117), the MPI form
+    with its reverse ADD scatter, on the reference's data files, 1-4 ranks; then the same after new values with the old pattern."""
+    import scipy.sparse as sp
+    from petsc_amd import petsc as P
+    g = load(golden_dir, name)
+    N = int(g["N"])
+    rng = np.random.default_rng(17)
+    xg, y0g = rng.standard_normal(N), rng.standard_normal(N)
+    a2 = g["a"] * rng.uniform(0.5, 2.0, len(g["a"]))
+
+    def body(comm):
+        rs, re = local_slice(comm, N)
+        A = P.Mat.from_global_csr(comm, g["i"], g["j"], g["a"])
+        x = P.Vec.from_array(comm, xg[rs:re], N)
+        y = x.duplicate()
+        A.mult_transpose(x, y)
+        out = [y.array()]
+        y0 = P.Vec.from_array(comm, y0g[rs:re], N)
+        z = x.duplicate()
+        A.mult_transpose_add(x, y0, z)
+        out.append(z.array())
+        A.mult_transpose_add(x, y0, y0)
+        out.append(y0.array())
+        with pytest.raises(P.PetscError) as e:
+            A.mult_transpose(x, x)
+        assert e.value.code == 73
+        # same nonzero pattern, new values: MatZeroEntries + MatSetValues + MatAssemblyEnd re-uploads values only
+        A.set_global_values(g["i"], g["j"], a2)
+        A.mult_transpose(x, y)
+        out.append(y.array())
+        for o in (x, y, y0, z, A):
+            o.destroy()
+        return out
+
+    res = run_ranks(size, body)
+    parts = [gather([r[k] for r in res]) for k in range(4)]
+    ref = sp.csr_matrix((g["a"], g["j"], g["i"]), shape=(N, N)).T @ xg
+    scale = np.abs(ref).max() + 1e-300
+    op = orc.operator(g["i"], g["j"], g["a"], size)
+    assert np.abs(parts[0] - ref).max() <= 1e-12 * scale
+    assert np.abs(parts[0] - op.mult_transpose(xg)).max() <= 1e-12 * scale
+    zo = op.mult_transpose(xg, y0g)
+    assert np.abs(parts[1] - zo).max() <= 1e-12 * (scale + 1) and np.abs(parts[2] - zo).max() <= 1e-12 * (scale + 1)
+    ref2 = sp.csr_matrix((a2, g["j"], g["i"]), shape=(N, N)).T @ xg
+    assert np.abs(parts[3] - ref2).max() <= 1e-12 * (np.abs(ref2).max() + 1e-300)
+
+
 def ksp_case(comm, ai, aj, aa, b_global, ksp_type, pc="jacobi", x0=None, **opts):
     from petsc_amd import petsc as P
     N = len(ai) - 1

@@ -198,6 +198,95 @@ def test_spmv_compressed_row(ctx, orc):
         np.testing.assert_array_equal(z, orc.matmultadd(ai, aj, aa, x, y0, cprow=(cpi, ridx)))
 
 
+def gpu_mult_transpose(ctx, ai, aj, aa, n, x, cprow=None, y0=None, inplace=False, tpr=0, fmt=0, new_values=None):
+    m = len(ai) - 1
+    A = ctx.mat_create(m, n, ai, aj, aa, cprow)
+    if tpr:
+        fmt = 1
+        ctx.check(ctx.lib.phip_mat_set_threads_per_row(A, tpr))
+    if fmt == 1:
+        ctx.check(ctx.lib.phip_mat_set_format(A, 1))
+    ai32, aj32, aa64 = np.ascontiguousarray(ai, np.int32), np.ascontiguousarray(aj, np.int32), np.ascontiguousarray(aa, np.float64)
+    import ctypes as C
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    ctx.check(ctx.lib.phip_mat_transpose_setup(A, ip(ai32), ip(aj32), dp(aa64)))
+    if new_values is not None:
+        nv = np.ascontiguousarray(new_values, np.float64)
+        ctx.check(ctx.lib.phip_mat_update_values(A, dp(nv)))
+    dx = ctx.to_device(x if m else np.zeros(1))
+    dy = ctx.to_device(np.full(max(n, 1), 7.25))
+    if y0 is None:
+        ctx.check(ctx.lib.phip_mat_mult_transpose(A, dx, dy))
+        out = ctx.to_host(dy, n)
+    else:
+        dy0 = ctx.to_device(y0 if n else np.zeros(1))
+        ctx.check(ctx.lib.phip_mat_mult_transpose_add(A, dx, dy0, dy0 if inplace else dy))
+        out = ctx.to_host(dy0 if inplace else dy, n)
+        ctx.free(dy0)
+    ctx.free(dx); ctx.free(dy)
+    ctx.check(ctx.lib.phip_mat_destroy(A))
+    return out
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_mult_transpose_golden(ctx, orc, golden_dir, name):
+    """y = A^T x and z = y + A^T x (aij.c:1207-1266) on the reference's data files: within 1e-12 of scipy's A.T @ x, and bit for bit
+    the oracle's scatter-add order when a row of the transposed copy is summed by one lane."""
+    import scipy.sparse as sp
+    g = load(golden_dir, name)
+    m, n = int(g["M"]), int(g["N"])
+    rng = np.random.default_rng(5)
+    x, y0 = rng.standard_normal(m), rng.standard_normal(n)
+    ref = sp.csr_matrix((g["a"], g["j"], g["i"]), shape=(m, n)).T @ x
+    yo = orc.matmulttranspose(g["i"], g["j"], g["a"], n, x)
+    assert relerr(yo, ref) <= 1e-13
+    assert relerr(gpu_mult_transpose(ctx, g["i"], g["j"], g["a"], n, x), ref) <= 1e-12
+    np.testing.assert_array_equal(gpu_mult_transpose(ctx, g["i"], g["j"], g["a"], n, x, tpr=1), yo)
+    zo = orc.matmulttranspose(g["i"], g["j"], g["a"], n, x, y=y0)
+    for inplace in (False, True):
+        np.testing.assert_array_equal(gpu_mult_transpose(ctx, g["i"], g["j"], g["a"], n, x, y0=y0, inplace=inplace, tpr=1), zo)
+        assert relerr(gpu_mult_transpose(ctx, g["i"], g["j"], g["a"], n, x, y0=y0, inplace=inplace), zo) <= 1e-12
+
+
+def test_mult_transpose_shapes(ctx, orc):
+    """Stencil matrices (the transposed copy is stencil-like too and takes the SELL-dict layout when eligible), a rectangular compressed-row matrix (the
+    off-diagonal block's shape), R-MAT, new values through phip_mat_update_values, and the call-order error."""
+    from petsc_amd import generators as G
+    from petsc_amd.capi import PhipError
+    rng = np.random.default_rng(6)
+    for ai, aj, aa in (G.convdiff3d_7pt(19, 13, 11), G.box3d_27pt(12), G.laplace2d_5pt(40, 23)):
+        n = len(ai) - 1
+        x = rng.standard_normal(n)
+        assert relerr(gpu_mult_transpose(ctx, ai, aj, aa, n, x), orc.matmulttranspose(ai, aj, aa, n, x)) <= 1e-12  # the library's layout choice
+        np.testing.assert_array_equal(gpu_mult_transpose(ctx, ai, aj, aa, n, x, tpr=1), orc.matmulttranspose(ai, aj, aa, n, x))
+        aa2 = aa * rng.uniform(0.5, 2.0, len(aa))
+        np.testing.assert_array_equal(gpu_mult_transpose(ctx, ai, aj, aa, n, x, tpr=1, new_values=aa2), orc.matmulttranspose(ai, aj, aa2, n, x))
+        assert relerr(gpu_mult_transpose(ctx, ai, aj, aa, n, x, new_values=aa2), orc.matmulttranspose(ai, aj, aa2, n, x)) <= 1e-12
+    ai, aj, aa = G.rmat(12)
+    n = len(ai) - 1
+    x = rng.standard_normal(n)
+    assert relerr(gpu_mult_transpose(ctx, ai, aj, aa, n, x), orc.matmulttranspose(ai, aj, aa, n, x)) <= 1e-12
+    m, n = 1000, 300
+    lens = np.where(rng.random(m) < 0.15, rng.integers(1, 9, m), 0)
+    ai = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    aj = np.concatenate([np.sort(rng.choice(n, L, replace=False)) for L in lens if L]).astype(np.int32)
+    aa = rng.standard_normal(len(aj))
+    use, cpi, ridx = orc.check_compressed_row(ai)
+    assert use
+    x, y0 = rng.standard_normal(m), rng.standard_normal(n)
+    np.testing.assert_array_equal(gpu_mult_transpose(ctx, ai, aj, aa, n, x, cprow=(cpi, ridx), tpr=1), orc.matmulttranspose(ai, aj, aa, n, x, cprow=(cpi, ridx)))
+    np.testing.assert_array_equal(gpu_mult_transpose(ctx, ai, aj, aa, n, x, cprow=(cpi, ridx), y0=y0, tpr=1), orc.matmulttranspose(ai, aj, aa, n, x, y=y0, cprow=(cpi, ridx)))
+    # empty matrix: A^T x = 0
+    z = gpu_mult_transpose(ctx, np.zeros(4, np.int32), np.zeros(0, np.int32), np.zeros(0), 5, np.ones(3))
+    np.testing.assert_array_equal(z, np.zeros(5))
+    A = ctx.mat_create(2, 2, np.array([0, 1, 2], np.int32), np.array([0, 1], np.int32), np.ones(2))
+    d = ctx.to_device(np.ones(2)); e = ctx.to_device(np.ones(2))
+    with pytest.raises(PhipError):
+        ctx.check(ctx.lib.phip_mat_mult_transpose(A, d, e))
+    ctx.free(d); ctx.free(e); ctx.check(ctx.lib.phip_mat_destroy(A))
+
+
 def test_plan_covers_rows(ctx):
     from petsc_amd import generators as G
     for ai, aj, aa in (G.laplace3d_7pt(20), G.rmat(12)):

@@ -89,6 +89,26 @@ def test_distributed_mult_equals_sequential(orc, golden_dir, name, size):
     assert np.abs(y1 - yp).max() <= 1e-13 * (np.abs(y1).max() + 1e-300)
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_matmulttranspose_vs_scipy(orc, golden_dir, name):
+    """MatMultTranspose(Add)_SeqAIJ (aij.c:1207-1266) and the MPIAIJ form with its reverse ADD scatter (mpiaij.c:1029-1056,
+    1102-1117) on the reference's data files, against scipy's A.T @ x (an independent implementation)."""
+    import scipy.sparse as sp
+    g = load(golden_dir, name)
+    M, N = int(g["M"]), int(g["N"])
+    rng = np.random.default_rng(3)
+    x, y0 = rng.standard_normal(M), rng.standard_normal(N)
+    ref = sp.csr_matrix((g["a"], g["j"], g["i"]), shape=(M, N)).T @ x
+    scale = np.abs(ref).max() + 1e-300
+    assert np.abs(orc.matmulttranspose(g["i"], g["j"], g["a"], N, x) - ref).max() <= 1e-14 * scale
+    assert np.abs(orc.matmulttranspose(g["i"], g["j"], g["a"], N, x, y=y0) - (y0 + ref)).max() <= 1e-13 * (scale + 1)
+    if M == N:
+        for size in (1, 2, 3, 4):
+            op = orc.operator(g["i"], g["j"], g["a"], size)
+            assert np.abs(op.mult_transpose(x) - ref).max() <= 1e-13 * scale
+            assert np.abs(op.mult_transpose(x, y0) - (y0 + ref)).max() <= 1e-13 * (scale + 1)
+
+
 def test_compressed_row(orc):
     ai = np.array([0, 0, 2, 2, 2, 3, 3, 3, 3, 3, 3], dtype=np.int32)  # 2 of 10 rows non-empty
     use, cpi, ridx = orc.check_compressed_row(ai)
