@@ -146,6 +146,10 @@ PetscErrorCode MatMultAdd(Mat A, Vec x, Vec y, Vec z);
 PetscErrorCode MatMultTranspose(Mat A, Vec x, Vec y);            /* matrix.c:2259; aij.c:1258, mpiaij.c:1029 */
 PetscErrorCode MatMultTransposeAdd(Mat A, Vec x, Vec y, Vec z);  /* matrix.c:2435; aij.c:1207, mpiaij.c:1102 */
 PetscErrorCode MatGetDiagonal(Mat A, Vec v);
+/* value updates with an unchanged nonzero pattern: host CSR updated, values only re-sent to the device */
+PetscErrorCode MatScale(Mat A, PetscScalar a);            /* matrix.c:4883; aij.c:2475, mpiaij.c:1139 */
+PetscErrorCode MatDiagonalScale(Mat A, Vec l, Vec r);     /* matrix.c:4832; aij.c:2200, mpiaij.c:2040 (l, r may be NULL) */
+PetscErrorCode MatShift(Mat A, PetscScalar a);            /* axpy.c:154; gcreate.c:6-24 */
 PetscErrorCode MatGetRowMaxAbs(Mat A, Vec v, PetscInt idx[]);
 PetscErrorCode MatGetRowSum(Mat A, Vec v);
 PetscErrorCode MatDestroy(Mat *A);

@@ -936,6 +936,9 @@ struct _MatOps { /* the _MatOps slots (include/petsc/private/matimpl.h:28-206) t
   PetscErrorCode (*multtranspose)(Mat, Vec, Vec);
   PetscErrorCode (*multtransposeadd)(Mat, Vec, Vec, Vec);
   PetscErrorCode (*getdiagonal)(Mat, Vec);
+  PetscErrorCode (*scale)(Mat, PetscScalar);
+  PetscErrorCode (*diagonalscale)(Mat, Vec, Vec);
+  PetscErrorCode (*shift)(Mat, PetscScalar);
   PetscErrorCode (*assemblyend)(Mat, MatAssemblyType);
   PetscErrorCode (*zeroentries)(Mat);
   PetscErrorCode (*getvecs)(Mat, Vec *, Vec *);
@@ -1062,6 +1065,47 @@ static PetscErrorCode MatZeroEntries_AIJHIP(Mat A)
   std::fill(A->B.a.begin(), A->B.a.end(), 0.0); A->B.values_dirty = true;
   return 0;
 }
+/* ---- value updates that keep the nonzero pattern: the host CSR is the master copy (as under the reference's GPU types, whose
+   interface routines mark the device copy stale: matrix.c:4850-4853, 4902-4905, axpy.c:166-169); only the VALUES travel to the device
+   afterwards (HostAIJ::upload -> phip_mat_update_values), also into the SELL-dict and transposed copies. ---- */
+static void aij_scale(HostAIJ &B, double alpha) /* MatScale_SeqAIJ aij.c:2475-2488: BLASscal over a->a */
+{
+  for (size_t k = 0; k < (size_t)B.nz; k++) B.a[k] *= alpha;
+  B.values_dirty = true;
+}
+static void aij_diagonal_scale(HostAIJ &B, const double *l, const double *r) /* MatDiagonalScale_SeqAIJ aij.c:2200-2235: rows by l, then entries by r[col] */
+{
+  if (l) for (PetscInt i = 0; i < B.m; i++) for (PetscInt k = B.ai[(size_t)i]; k < B.ai[(size_t)i + 1]; k++) B.a[(size_t)k] *= l[i];
+  if (r) for (size_t k = 0; k < (size_t)B.nz; k++) B.a[k] *= r[B.j[k]];
+  B.values_dirty = true;
+}
+static PetscErrorCode mat_upload_values(Mat A)
+{
+  PetscErrorCode ierr = A->A.upload(MCTX(A)); CHKERRQ(ierr);
+  if (A->mpi) { ierr = A->B.upload(MCTX(A)); CHKERRQ(ierr); }
+  return 0;
+}
+static PetscErrorCode MatScale_AIJHIP(Mat A, PetscScalar a) /* aij.c:2475 / MatScale_MPIAIJ mpiaij.c:1139-1148: both blocks */
+{
+  aij_scale(A->A, a);
+  if (A->mpi) aij_scale(A->B, a);
+  return mat_upload_values(A);
+}
+static PetscErrorCode MatDiagonalScale_SeqAIJHIP(Mat A, Vec ll, Vec rr)
+{
+  if (ll && ll->n != A->m) SETERRQ(PETSC_ERR_ARG_SIZ, "Left scaling vector wrong length");
+  if (rr && rr->n != A->n) SETERRQ(PETSC_ERR_ARG_SIZ, "Right scaling vector wrong length");
+  const PetscScalar *l = NULL, *r = NULL;
+  PetscErrorCode     ierr;
+  if (ll) { ierr = VecGetArrayRead(ll, &l); CHKERRQ(ierr); }
+  if (rr && rr != ll) { ierr = VecGetArrayRead(rr, &r); CHKERRQ(ierr); } else if (rr) r = l;
+  aij_diagonal_scale(A->A, l, r);
+  if (rr && rr != ll) { ierr = VecRestoreArrayRead(rr, &r); CHKERRQ(ierr); }
+  if (ll) { ierr = VecRestoreArrayRead(ll, &l); CHKERRQ(ierr); }
+  return mat_upload_values(A);
+}
+static PetscErrorCode MatShift_AIJHIP(Mat A, PetscScalar a); /* below MatSetValues / MatAssemblyEnd */
+
 static PetscErrorCode MatCreateVecs_AIJHIP(Mat A, Vec *right, Vec *left) /* MatCreateVecs_SeqAIJCUSP aijcusp.cu:287-309 */
 {
   PetscErrorCode ierr;
@@ -1092,6 +1136,7 @@ static PetscErrorCode MatCreate_SeqAIJHIP(Mat A)
   PetscErrorCode ierr = mat_layouts(A); CHKERRQ(ierr);
   A->ops.setvalues = MatSetValues_SeqAIJHIP; A->ops.mult = MatMult_SeqAIJHIP; A->ops.multadd = MatMultAdd_SeqAIJHIP;
   A->ops.multtranspose = MatMultTranspose_SeqAIJHIP; A->ops.multtransposeadd = MatMultTransposeAdd_SeqAIJHIP;
+  A->ops.scale = MatScale_AIJHIP; A->ops.diagonalscale = MatDiagonalScale_SeqAIJHIP; A->ops.shift = MatShift_AIJHIP;
   A->ops.getdiagonal = MatGetDiagonal_SeqAIJHIP; A->ops.assemblyend = MatAssemblyEnd_SeqAIJHIP; A->ops.zeroentries = MatZeroEntries_AIJHIP;
   A->ops.getvecs = MatCreateVecs_AIJHIP; A->ops.destroy = MatDestroy_AIJHIP;
   A->type = MATSEQAIJHIP; A->type_set = true; A->mpi = false;
@@ -1298,6 +1343,28 @@ static PetscErrorCode MatMultTransposeAdd_MPIAIJHIP(Mat A, Vec x, Vec y, Vec z)
   CHKPHIP(phip_halo_reverse_end(A->halo, z->d));
   return 0;
 }
+/* MatDiagonalScale_MPIAIJ mpiaij.c:2040-2069: the right vector's ghost values come through the same scatter as MatMult's */
+static PetscErrorCode MatDiagonalScale_MPIAIJHIP(Mat A, Vec ll, Vec rr)
+{
+  if (rr && rr->n != A->n) SETERRQ(PETSC_ERR_ARG_SIZ, "right vector non-conforming local size");
+  if (ll && ll->n != A->m) SETERRQ(PETSC_ERR_ARG_SIZ, "left vector non-conforming local size");
+  PetscErrorCode      ierr;
+  std::vector<double> ghost(A->garray.size() + 1);
+  if (rr) {
+    CHKPHIP(phip_halo_begin(A->halo, rr->d, A->lvec));
+    CHKPHIP(phip_halo_end(A->halo));
+    if (!A->garray.empty()) CHKPHIP(phip_memcpy_d2h(MCTX(A), ghost.data(), A->lvec, sizeof(double) * A->garray.size()));
+  }
+  const PetscScalar *l = NULL, *r = NULL;
+  if (ll) { ierr = VecGetArrayRead(ll, &l); CHKERRQ(ierr); }
+  if (rr && rr != ll) { ierr = VecGetArrayRead(rr, &r); CHKERRQ(ierr); } else if (rr) r = l;
+  if (ll) aij_diagonal_scale(A->B, l, NULL);
+  aij_diagonal_scale(A->A, l, r);
+  if (rr) aij_diagonal_scale(A->B, NULL, ghost.data());
+  if (rr && rr != ll) { ierr = VecRestoreArrayRead(rr, &r); CHKERRQ(ierr); }
+  if (ll) { ierr = VecRestoreArrayRead(ll, &l); CHKERRQ(ierr); }
+  return mat_upload_values(A);
+}
 /* MatGetDiagonal_MPIAIJ mpiaij.c:1125-1135 */
 static PetscErrorCode MatGetDiagonal_MPIAIJHIP(Mat A, Vec v)
 {
@@ -1312,6 +1379,7 @@ static PetscErrorCode MatCreate_MPIAIJHIP(Mat A)
   PetscErrorCode ierr = mat_layouts(A); CHKERRQ(ierr);
   A->ops.setvalues = MatSetValues_MPIAIJHIP; A->ops.mult = MatMult_MPIAIJHIP; A->ops.multadd = MatMultAdd_MPIAIJHIP;
   A->ops.multtranspose = MatMultTranspose_MPIAIJHIP; A->ops.multtransposeadd = MatMultTransposeAdd_MPIAIJHIP;
+  A->ops.scale = MatScale_AIJHIP; A->ops.diagonalscale = MatDiagonalScale_MPIAIJHIP; A->ops.shift = MatShift_AIJHIP;
   A->ops.getdiagonal = MatGetDiagonal_MPIAIJHIP; A->ops.assemblyend = MatAssemblyEnd_MPIAIJHIP; A->ops.zeroentries = MatZeroEntries_AIJHIP;
   A->ops.getvecs = MatCreateVecs_AIJHIP; A->ops.destroy = MatDestroy_AIJHIP;
   A->type = MATMPIAIJHIP; A->type_set = true; A->mpi = true;
@@ -1519,6 +1587,42 @@ extern "C" PetscErrorCode MatMultAdd(Mat A, Vec v1, Vec v2, Vec v3) /* matrix.c:
   PetscErrorCode ierr = (*A->ops.multadd)(A, v1, v2, v3); CHKERRQ(ierr);
   v3->state++;
   return 0;
+}
+/* MatShift_SeqAIJ aij.c:3064-3075 / MatShift_MPIAIJ mpiaij.c:2589-2601 -> MatShift_Basic gcreate.c:6-24: ADD a to every owned (i,i), assemble */
+static PetscErrorCode MatShift_AIJHIP(Mat A, PetscScalar a)
+{
+  const PetscInt rstart = A->rrange[(size_t)A->comm->rank], rend = A->rrange[(size_t)A->comm->rank + 1];
+  PetscErrorCode ierr;
+  for (PetscInt i = rstart; i < rend; i++) { ierr = MatSetValues(A, 1, &i, 1, &i, &a, ADD_VALUES); CHKERRQ(ierr); }
+  ierr = MatAssemblyBegin(A, MAT_FINAL_ASSEMBLY); CHKERRQ(ierr);
+  return MatAssemblyEnd(A, MAT_FINAL_ASSEMBLY);
+}
+extern "C" PetscErrorCode MatScale(Mat A, PetscScalar a) /* matrix.c:4883-4913 */
+{
+  MatCheckAssembled(A, "MatScale");
+  if (a != 1.0) {
+    if (!A->ops.scale) SETERRQ(PETSC_ERR_SUP, "Mat type %s", A->type.c_str());
+    PetscErrorCode ierr = (*A->ops.scale)(A, a); CHKERRQ(ierr);
+    A->state++;
+  }
+  return 0;
+}
+extern "C" PetscErrorCode MatDiagonalScale(Mat A, Vec l, Vec r) /* matrix.c:4832-4861 */
+{
+  MatCheck(A, "MatDiagonalScale");
+  if (!A->ops.diagonalscale) SETERRQ(PETSC_ERR_SUP, "Mat type %s", A->type.c_str());
+  if (!A->assembled) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Not for unassembled matrix");
+  if (l) VecCheckReady(l, "MatDiagonalScale");
+  if (r) VecCheckReady(r, "MatDiagonalScale");
+  PetscErrorCode ierr = (*A->ops.diagonalscale)(A, l, r); CHKERRQ(ierr);
+  A->state++;
+  return 0;
+}
+extern "C" PetscErrorCode MatShift(Mat A, PetscScalar a) /* axpy.c:154-177 */
+{
+  MatCheckAssembled(A, "MatShift");
+  if (!A->ops.shift) SETERRQ(PETSC_ERR_SUP, "Mat type %s", A->type.c_str());
+  return (*A->ops.shift)(A, a);
 }
 extern "C" PetscErrorCode MatMultTranspose(Mat A, Vec x, Vec y) /* matrix.c:2259-2288 */
 {

@@ -440,6 +440,9 @@ class Mat:
     def mult_transpose(self, x, y): chk(lib().MatMultTranspose(self.h, x.h, y.h))
     def mult_transpose_add(self, x, y, z): chk(lib().MatMultTransposeAdd(self.h, x.h, y.h, z.h))
     def get_diagonal(self, v): chk(lib().MatGetDiagonal(self.h, v.h))
+    def scale(self, a): chk(lib().MatScale(self.h, float(a)))
+    def diagonal_scale(self, l=None, r=None): chk(lib().MatDiagonalScale(self.h, l.h if l is not None else None, r.h if r is not None else None))
+    def shift(self, a): chk(lib().MatShift(self.h, float(a)))
     def get_row_max_abs(self, v): chk(lib().MatGetRowMaxAbs(self.h, v.h, None))
     def get_row_sum(self, v): chk(lib().MatGetRowSum(self.h, v.h))
 
