@@ -117,6 +117,8 @@ PetscErrorCode VecReciprocal(Vec x);
 PetscErrorCode VecDot(Vec x, Vec y, PetscScalar *val);
 PetscErrorCode VecTDot(Vec x, Vec y, PetscScalar *val);
 PetscErrorCode VecMDot(Vec x, PetscInt nv, const Vec y[], PetscScalar val[]);
+PetscErrorCode VecMTDot(Vec x, PetscInt nv, const Vec y[], PetscScalar val[]);       /* rvector.c:1178 */
+PetscErrorCode VecDotNorm2(Vec s, Vec t, PetscScalar *dp, PetscReal *nm);           /* vinv.c:1369: dp = s.t, nm = t.t */
 PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val);
 PetscErrorCode VecNormalize(Vec x, PetscReal *val);
 

@@ -327,8 +327,95 @@ static PetscErrorCode VecCopy_HIP(Vec x,Vec y)                                 /
   VEC_DONE(y,py);
   PetscFunctionReturn(0);
 }
-/* axpby, axpbypcz, pointwisedivide, swap, reciprocal, tdot (= dot for real scalars), mtdot, dotnorm2: the same three lines around
-   phip_vec_axpby / _axpbypcz / _pointwise_divide / _swap / _reciprocal; omitted here for brevity, listed in INTEGRATION.md section 3. */
+static PetscErrorCode VecAXPBY_HIP(Vec y,PetscScalar a,PetscScalar b,Vec x)    /* bvec1.c:99-133 */
+{
+  PetscErrorCode ierr; const PetscScalar *px; PetscScalar *py;
+  PetscFunctionBegin;
+  VEC_R(x,px); VEC_RW(y,py);
+  CHKERRPHIP(phip_vec_axpby(hipctx,y->map->n,py,a,b,px));
+  VEC_DONE(y,py);
+  PetscFunctionReturn(0);
+}
+static PetscErrorCode VecAXPBYPCZ_HIP(Vec z,PetscScalar a,PetscScalar b,PetscScalar c,Vec x,Vec y)   /* bvec1.c:137-165 */
+{
+  PetscErrorCode ierr; const PetscScalar *px,*py; PetscScalar *pz;
+  PetscFunctionBegin;
+  VEC_R(x,px); VEC_R(y,py); VEC_RW(z,pz);
+  CHKERRPHIP(phip_vec_axpbypcz(hipctx,z->map->n,pz,a,b,c,px,py));
+  VEC_DONE(z,pz);
+  ierr = PetscLogFlops(5.0*z->map->n);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
+static PetscErrorCode VecPointwiseDivide_HIP(Vec w,Vec x,Vec y)                /* bvec2.c:114-132 */
+{
+  PetscErrorCode ierr; const PetscScalar *px,*py; PetscScalar *pw;
+  PetscFunctionBegin;
+  VEC_R(x,px); VEC_R(y,py);
+  if (w == x || w == y) { VEC_RW(w,pw); } else { VEC_W(w,pw); }
+  CHKERRPHIP(phip_vec_pointwise_divide(hipctx,w->map->n,pw,px,py));
+  VEC_DONE(w,pw);
+  ierr = PetscLogFlops(w->map->n);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
+static PetscErrorCode VecSwap_HIP(Vec x,Vec y)                                 /* bvec2.c:211-227 */
+{
+  PetscErrorCode ierr; PetscScalar *px,*py;
+  PetscFunctionBegin;
+  if (x == y) PetscFunctionReturn(0);
+  VEC_RW(x,px); VEC_RW(y,py);
+  CHKERRPHIP(phip_vec_swap(hipctx,x->map->n,px,py));
+  VEC_DONE(x,px); VEC_DONE(y,py);
+  PetscFunctionReturn(0);
+}
+static PetscErrorCode VecReciprocal_HIP(Vec x)                                 /* vinv.c:1213-1227 */
+{
+  PetscErrorCode ierr; PetscScalar *px;
+  PetscFunctionBegin;
+  VEC_RW(x,px);
+  CHKERRPHIP(phip_vec_reciprocal(hipctx,x->map->n,px));
+  VEC_DONE(x,px);
+  PetscFunctionReturn(0);
+}
+static PetscErrorCode VecDotNorm2_HIP(Vec s,Vec t,PetscScalar *dp,PetscScalar *nm)   /* vinv.c:1388-1390: dp = s.t, nm = t.t, one fused pass */
+{
+  PetscErrorCode ierr; Vec ys[2]; PetscScalar z[2];
+  PetscFunctionBegin;
+  ys[0] = s; ys[1] = t;
+  ierr = VecMDot_HIP(t,2,ys,z);CHKERRQ(ierr);
+  *dp = z[0]; *nm = z[1];
+  PetscFunctionReturn(0);
+}
+static PetscErrorCode VecConjugate_HIP(Vec x) { PetscFunctionBegin; PetscFunctionReturn(0); }   /* real scalars */
+/* placearray / replacearray / resetarray (veccusp.cu:1974-1976): bring the host copy up to date, let the Seq/MPI routine swap the host
+   pointer (bvec2.c:687-735, pbvec.c:60-97), and mark the host copy as the valid one so the next device op uploads it */
+static PetscErrorCode VecPlaceArray_HIP(Vec v,const PetscScalar *a)
+{
+  PetscErrorCode ierr;
+  PetscFunctionBegin;
+  ierr = VecHIPSyncToCPU(v);CHKERRQ(ierr);
+  if (VHIP(v)->ismpi) { ierr = VecPlaceArray_MPI(v,a);CHKERRQ(ierr); } else { ierr = VecPlaceArray_Seq(v,a);CHKERRQ(ierr); }
+  VHIP(v)->valid = VHIP_CPU;
+  PetscFunctionReturn(0);
+}
+static PetscErrorCode VecResetArray_HIP(Vec v)
+{
+  PetscErrorCode ierr;
+  PetscFunctionBegin;
+  ierr = VecHIPSyncToCPU(v);CHKERRQ(ierr);
+  if (VHIP(v)->ismpi) { ierr = VecResetArray_MPI(v);CHKERRQ(ierr); } else { ierr = VecResetArray_Seq(v);CHKERRQ(ierr); }
+  VHIP(v)->valid = VHIP_CPU;
+  PetscFunctionReturn(0);
+}
+static PetscErrorCode VecReplaceArray_HIP(Vec v,const PetscScalar *a)
+{
+  PetscErrorCode ierr;
+  PetscFunctionBegin;
+  ierr = VecHIPSyncToCPU(v);CHKERRQ(ierr);
+  if (VHIP(v)->ismpi) SETERRQ(PETSC_COMM_SELF,PETSC_ERR_SUP,"VecReplaceArray on VECMPIHIP"); /* Vec_MPI has no replacearray either (pbvec.c:101-171) */
+  ierr = VecReplaceArray_Seq(v,a);CHKERRQ(ierr);
+  VHIP(v)->valid = VHIP_CPU;
+  PetscFunctionReturn(0);
+}
 
 static PetscErrorCode VecDestroy_HIP(Vec v)
 {
@@ -379,7 +466,11 @@ static PetscErrorCode VecCreate_HIP_Private(Vec V,PetscBool ismpi,const char *ty
   V->ops->dot_local = VecDot_HIP; V->ops->tdot_local = VecDot_HIP; V->ops->norm_local = VecNorm_HIP; V->ops->mdot_local = VecMDot_HIP;
   V->ops->axpy = VecAXPY_HIP;   V->ops->aypx = VecAYPX_HIP;     V->ops->waxpy = VecWAXPY_HIP; V->ops->maxpy = VecMAXPY_HIP;
   V->ops->pointwisemult = VecPointwiseMult_HIP; V->ops->scale = VecScale_HIP; V->ops->set = VecSet_HIP; V->ops->copy = VecCopy_HIP;
+  V->ops->axpby = VecAXPBY_HIP; V->ops->axpbypcz = VecAXPBYPCZ_HIP; V->ops->pointwisedivide = VecPointwiseDivide_HIP; V->ops->swap = VecSwap_HIP;
+  V->ops->reciprocal = VecReciprocal_HIP; V->ops->dotnorm2 = VecDotNorm2_HIP; V->ops->conjugate = VecConjugate_HIP;
+  V->ops->placearray = VecPlaceArray_HIP; V->ops->resetarray = VecResetArray_HIP; V->ops->replacearray = VecReplaceArray_HIP;
   V->ops->duplicate = VecDuplicate_HIP;        V->ops->destroy = VecDestroy_HIP;
+  /* every other slot keeps the Seq/MPI routine, which reaches the data through VecGetArray[Read] and therefore through the accessors above */
   ierr = PetscObjectChangeTypeName((PetscObject)V,type);CHKERRQ(ierr);
   PetscFunctionReturn(0);
 }
@@ -403,7 +494,7 @@ PETSC_EXTERN PetscErrorCode VecCreate_HIP(Vec V)            /* mpicusp.cu:237-25
 }
 
 /* ---- Mat ----------------------------------------------------------------------------------------------------- */
-typedef struct { phip_mat dev; PetscObjectState state,nonzerostate; } Mat_SeqAIJHIP;          /* B->spptr of the Seq type */
+typedef struct { phip_mat dev,tdev; PetscObjectState state,nonzerostate; } Mat_SeqAIJHIP;          /* B->spptr of the Seq type */
 typedef struct { phip_halo halo; PetscObjectState nonzerostate; } Mat_MPIAIJHIP;              /* Mat_MPIAIJ.spptr (mpiaij.h:77) */
 
 static PetscErrorCode MatHIPCopyToGPU(Mat A)                /* role of MatCUSPCopyToGPU aijcusp.cu:110-208 */
@@ -418,6 +509,7 @@ static PetscErrorCode MatHIPCopyToGPU(Mat A)                /* role of MatCUSPCo
     if (h->state != st) CHKERRPHIP(phip_mat_update_values(h->dev,a->a));
   } else {
     if (h->dev) CHKERRPHIP(phip_mat_destroy(h->dev));
+    h->tdev = NULL;                                              /* the transposed copy went with it */
     CHKERRPHIP(phip_mat_create(hipctx,A->rmap->n,A->cmap->n,a->i,a->j,a->a,a->compressedrow.use,a->compressedrow.nrows,
                                a->compressedrow.i,a->compressedrow.rindex,&h->dev));
     h->nonzerostate = A->nonzerostate;
@@ -452,6 +544,39 @@ static PetscErrorCode MatMultAdd_SeqAIJHIP(Mat A,Vec xx,Vec yy,Vec zz)   /* aij.
   if (yy == zz) { VEC_RW(zz,z); y = z; } else { VEC_R(yy,y); VEC_W(zz,z); }
   CHKERRPHIP(phip_mat_multadd(((Mat_SeqAIJHIP*)A->spptr)->dev,x,y,z));
   VEC_DONE(zz,z);
+  ierr = PetscLogFlops(2.0*((Mat_SeqAIJ*)A->data)->nz);CHKERRQ(ierr);
+  PetscFunctionReturn(0);
+}
+/* transposed products: the first call builds the transposed device copy from the host CSR (phip_mat_transpose_setup); it lives and dies
+   with the device matrix and follows phip_mat_update_values */
+static PetscErrorCode MatHIPNeedTranspose(Mat A)
+{
+  Mat_SeqAIJ *a = (Mat_SeqAIJ*)A->data; Mat_SeqAIJHIP *h = (Mat_SeqAIJHIP*)A->spptr; PetscErrorCode ierr;
+  PetscFunctionBegin;
+  ierr = MatHIPCopyToGPU(A);CHKERRQ(ierr);
+  if (h->tdev != h->dev) { CHKERRPHIP(phip_mat_transpose_setup(h->dev,a->i,a->j,a->a)); h->tdev = h->dev; }
+  PetscFunctionReturn(0);
+}
+static PetscErrorCode MatMultTransposeAdd_SeqAIJHIP(Mat A,Vec xx,Vec yy,Vec zz)   /* aij.c:1207-1254 */
+{
+  PetscErrorCode ierr; const PetscScalar *x,*y; PetscScalar *z;
+  PetscFunctionBegin;
+  ierr = MatHIPNeedTranspose(A);CHKERRQ(ierr);
+  VEC_R(xx,x);
+  if (yy == zz) { VEC_RW(zz,z); y = z; } else { VEC_R(yy,y); VEC_W(zz,z); }
+  CHKERRPHIP(phip_mat_mult_transpose_add(((Mat_SeqAIJHIP*)A->spptr)->dev,x,y,z));
+  VEC_DONE(zz,z);
+  ierr = PetscLogFlops(2.0*((Mat_SeqAIJ*)A->data)->nz);CHKERRQ(ierr);      /* aij.c:1250 */
+  PetscFunctionReturn(0);
+}
+static PetscErrorCode MatMultTranspose_SeqAIJHIP(Mat A,Vec xx,Vec yy)       /* aij.c:1258-1266 */
+{
+  PetscErrorCode ierr; const PetscScalar *x; PetscScalar *y;
+  PetscFunctionBegin;
+  ierr = MatHIPNeedTranspose(A);CHKERRQ(ierr);
+  VEC_R(xx,x); VEC_W(yy,y);
+  CHKERRPHIP(phip_mat_mult_transpose(((Mat_SeqAIJHIP*)A->spptr)->dev,x,y));
+  VEC_DONE(yy,y);
   ierr = PetscLogFlops(2.0*((Mat_SeqAIJ*)A->data)->nz);CHKERRQ(ierr);
   PetscFunctionReturn(0);
 }
@@ -513,6 +638,9 @@ PETSC_EXTERN PetscErrorCode MatCreate_SeqAIJHIP(Mat B)
   B->ops->mult = MatMult_SeqAIJHIP;               B->ops->multadd = MatMultAdd_SeqAIJHIP;
   B->ops->getdiagonal = MatGetDiagonal_SeqAIJHIP; B->ops->assemblyend = MatAssemblyEnd_SeqAIJHIP;
   B->ops->destroy = MatDestroy_SeqAIJHIP;         B->ops->getvecs = MatCreateVecs_AIJHIP;
+  B->ops->multtranspose = MatMultTranspose_SeqAIJHIP; B->ops->multtransposeadd = MatMultTransposeAdd_SeqAIJHIP;
+  /* scale, diagonalscale, shift, zeroentries, setvalues ... stay the SeqAIJ host routines: they bump the object state, and
+     MatHIPCopyToGPU re-sends the values (only) before the next product */
   ierr = PetscObjectChangeTypeName((PetscObject)B,MATSEQAIJHIP);CHKERRQ(ierr);
   PetscFunctionReturn(0);
 }
@@ -577,6 +705,40 @@ static PetscErrorCode MatMult_MPIAIJHIP(Mat A,Vec xx,Vec yy)   /* mpiaij.c:984-9
   if (square) { ierr = VecHIPByProductRecord(yy,2,&t,xx,NULL);CHKERRQ(ierr); }
   PetscFunctionReturn(0);
 }
+static PetscErrorCode MatMultAdd_MPIAIJHIP(Mat A,Vec xx,Vec yy,Vec zz)   /* mpiaij.c:1014-1025 */
+{
+  Mat_MPIAIJ    *a = (Mat_MPIAIJ*)A->data; Mat_MPIAIJHIP *h = (Mat_MPIAIJHIP*)a->spptr; PetscErrorCode ierr;
+  const PetscScalar *x,*y; PetscScalar *z,*l;
+  PetscFunctionBegin;
+  ierr = MatHIPCopyToGPU(a->A);CHKERRQ(ierr); ierr = MatHIPCopyToGPU(a->B);CHKERRQ(ierr);
+  VEC_R(xx,x); VEC_W(a->lvec,l);
+  if (yy == zz) { VEC_RW(zz,z); y = z; } else { VEC_R(yy,y); VEC_W(zz,z); }
+  CHKERRPHIP(phip_halo_begin(h->halo,x,l));
+  CHKERRPHIP(phip_mat_multadd(((Mat_SeqAIJHIP*)a->A->spptr)->dev,x,y,z));
+  CHKERRPHIP(phip_halo_end(h->halo));
+  CHKERRPHIP(phip_mat_multadd(((Mat_SeqAIJHIP*)a->B->spptr)->dev,l,z,z));
+  VEC_DONE(a->lvec,l); VEC_DONE(zz,z);
+  PetscFunctionReturn(0);
+}
+/* mpiaij.c:1029-1056 / 1102-1117: lvec = B^T x; reverse scatter with ADD_VALUES begins; the diagonal block's transposed product runs
+   meanwhile; the scatter's end adds the ghost contributions (yy == NULL: MatMultTranspose) */
+static PetscErrorCode MatMultTransposeAdd_MPIAIJHIP(Mat A,Vec xx,Vec yy,Vec zz)
+{
+  Mat_MPIAIJ    *a = (Mat_MPIAIJ*)A->data; Mat_MPIAIJHIP *h = (Mat_MPIAIJHIP*)a->spptr; PetscErrorCode ierr;
+  const PetscScalar *x,*y = NULL; PetscScalar *z,*l;
+  PetscFunctionBegin;
+  ierr = MatHIPNeedTranspose(a->A);CHKERRQ(ierr); ierr = MatHIPNeedTranspose(a->B);CHKERRQ(ierr);
+  VEC_R(xx,x); VEC_W(a->lvec,l);
+  if (yy && yy == zz) { VEC_RW(zz,z); y = z; } else { if (yy) { VEC_R(yy,y); } VEC_W(zz,z); }
+  CHKERRPHIP(phip_mat_mult_transpose(((Mat_SeqAIJHIP*)a->B->spptr)->dev,x,l));
+  CHKERRPHIP(phip_halo_reverse_begin(h->halo,l));
+  if (yy) CHKERRPHIP(phip_mat_mult_transpose_add(((Mat_SeqAIJHIP*)a->A->spptr)->dev,x,y,z));
+  else    CHKERRPHIP(phip_mat_mult_transpose(((Mat_SeqAIJHIP*)a->A->spptr)->dev,x,z));
+  CHKERRPHIP(phip_halo_reverse_end(h->halo,z));
+  VEC_DONE(a->lvec,l); VEC_DONE(zz,z);
+  PetscFunctionReturn(0);
+}
+static PetscErrorCode MatMultTranspose_MPIAIJHIP(Mat A,Vec xx,Vec yy) { return MatMultTransposeAdd_MPIAIJHIP(A,xx,NULL,yy); }
 static PetscErrorCode MatDestroy_MPIAIJHIP(Mat A)
 {
   Mat_MPIAIJ *a = (Mat_MPIAIJ*)A->data; Mat_MPIAIJHIP *h = (Mat_MPIAIJHIP*)a->spptr; PetscErrorCode ierr;
@@ -598,7 +760,9 @@ PETSC_EXTERN PetscErrorCode MatCreate_MPIAIJHIP(Mat B)       /* mpiaijcusp.cu:19
   ierr = PetscObjectComposeFunction((PetscObject)B,"MatMPIAIJSetPreallocation_C",MatMPIAIJSetPreallocation_MPIAIJHIP);CHKERRQ(ierr);
   B->ops->mult = MatMult_MPIAIJHIP;  B->ops->assemblyend = MatAssemblyEnd_MPIAIJHIP;
   B->ops->getvecs = MatCreateVecs_AIJHIP; B->ops->destroy = MatDestroy_MPIAIJHIP;
-  /* multadd: the same four calls with phip_mat_multadd on the diagonal block; getdiagonal is inherited (MatGetDiagonal(a->A), mpiaij.c:1125-1135) */
+  B->ops->multadd = MatMultAdd_MPIAIJHIP; B->ops->multtranspose = MatMultTranspose_MPIAIJHIP; B->ops->multtransposeadd = MatMultTransposeAdd_MPIAIJHIP;
+  /* getdiagonal is inherited (MatGetDiagonal(a->A), mpiaij.c:1125-1135) and lands in MatGetDiagonal_SeqAIJHIP; scale / diagonalscale / shift
+     stay MatScale_MPIAIJ etc., which call the blocks' host routines (mpiaij.c:1139-1148, 2040-2069, 2589-2601) */
   ierr = PetscObjectChangeTypeName((PetscObject)B,MATMPIAIJHIP);CHKERRQ(ierr);
   PetscFunctionReturn(0);
 }

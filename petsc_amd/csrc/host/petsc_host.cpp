@@ -749,6 +749,22 @@ extern "C" PetscErrorCode VecMDot(Vec x, PetscInt nv, const Vec y[], PetscScalar
   for (PetscInt k = 0; k < nv; k++) { VecCheckReady(y[k], "VecMDot"); VecCheckSame(x, y[k], "VecMDot"); }
   return (*x->ops.mdot)(x, nv, y, val);
 }
+/* VecMTDot rvector.c:1178-1207: no conjugation -- the same kernel for real scalars (the CUSP types alias it too) */
+extern "C" PetscErrorCode VecMTDot(Vec x, PetscInt nv, const Vec y[], PetscScalar val[]) { return VecMDot(x, nv, y, val); }
+/* VecDotNorm2 vinv.c:1369-1413 (ops->dotnorm2, veccusp.cu:1973): dp = sum s_i t_i, nm = sum t_i^2 (NOT its square root), one pass and
+   one reduction: the fused multi-dot with x = t, y = {s, t} */
+extern "C" PetscErrorCode VecDotNorm2(Vec s, Vec t, PetscScalar *dp, PetscReal *nm)
+{
+  VecCheckReady(s, "VecDotNorm2"); VecCheckReady(t, "VecDotNorm2");
+  if (!dp || !nm) SETERRQ(PETSC_ERR_ARG_NULL, "VecDotNorm2: null result");
+  if (s->N != t->N) SETERRQ(PETSC_ERR_ARG_INCOMP, "Incompatible vector global lengths");
+  if (s->n != t->n) SETERRQ(PETSC_ERR_ARG_INCOMP, "Incompatible vector local lengths");
+  const Vec      ys[2] = {s, t};
+  PetscScalar    z[2];
+  PetscErrorCode ierr = (*t->ops.mdot)(t, 2, ys, z); CHKERRQ(ierr);
+  *dp = z[0]; *nm = z[1];
+  return 0;
+}
 extern "C" PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val)
 {
   VecCheckReady(x, "VecNorm");

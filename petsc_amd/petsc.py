@@ -315,6 +315,18 @@ class Vec:
         chk(lib().VecMDot(self.h, len(ys), arr, _p(z)))
         return z
 
+    def mtdot(self, ys):
+        arr = (C.c_void_p * max(len(ys), 1))(*[y.h for y in ys])
+        z = np.zeros(len(ys))
+        chk(lib().VecMTDot(self.h, len(ys), arr, _p(z)))
+        return z
+
+    def dot_norm2(self, t):
+        """VecDotNorm2(self, t): (self . t, t . t)."""
+        dp, nm = C.c_double(), C.c_double()
+        chk(lib().VecDotNorm2(self.h, t.h, C.byref(dp), C.byref(nm)))
+        return dp.value, nm.value
+
     def norm(self, ntype=NORM_2):
         z = (C.c_double * 2)()
         chk(lib().VecNorm(self.h, ntype, z))

@@ -114,6 +114,10 @@ def test_vec_closed_forms_ex1():
         n1, n2 = x.norm(P.NORM_1_AND_2)
         assert n1 == 15.0 * n and abs(n2 - 15 * np.sqrt(n)) < 1e-12 * n
         assert abs(x.normalize() - 15 * np.sqrt(n)) < 1e-12 * n and abs(x.norm() - 1.0) < 1e-14
+        # VecDotNorm2 (vinv.c:1369-1413): (s.t, t.t); VecMTDot = VecMDot for real scalars
+        x.set(two); y.set(three)
+        assert x.dot_norm2(y) == (6.0 * n, 9.0 * n)
+        np.testing.assert_array_equal(x.mtdot(z), x.mdot(z))
         with pytest.raises(P.PetscError) as e:
             x.axpy(1.0, x)
         assert e.value.code == 61
