@@ -155,6 +155,9 @@ int phip_jacobi_setup(phip_ctx ctx, int32_t n, double *d_diag, int useabs, int s
  * a host round trip; phip_read_scalars then brings the final values to the host.
  * kind: 0 dot(x,y[0]) / mdot(x,y[0..nv-1]);  1 sum x_i^2 (nv=1);  2 sum |x_i| ;  3 max |x_i| (NaN propagates);  4 {sum|x|, sum x^2} */
 int phip_vec_reduce_local(phip_ctx ctx, int kind, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *d_out);
+/* the same local results delivered to HOST memory (one launch, pinned slot, no stream synchronize): the input of
+ * phip_comm_allreduce_host.  Raw sums: kind 1 returns sum x^2, not its square root. */
+int phip_vec_reduce_local_host(phip_ctx ctx, int kind, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *h_out);
 int phip_read_scalars(phip_ctx ctx, const double *d_src, int32_t n, double *h_dst);
 
 /* ---- by-product reductions --------------------------------------------------------------------------
@@ -171,8 +174,9 @@ typedef struct { int32_t slot, nvals; uint64_t seq; } phip_ticket;
 int phip_vec_pointwise_mult_reduce(phip_ctx ctx, int32_t n, double *d_w, const double *d_x, const double *d_y, int publish, phip_ticket *t);
 /* y = A x (phip_mat_mult); value {sum_i v_i y_i}, d_v has m entries (the caller passes x for a square matrix) */
 int phip_mat_mult_dot(phip_mat A, const double *d_x, double *d_y, const double *d_v, int publish, phip_ticket *t);
-/* y += A x in place (phip_mat_multadd with z == y, mpiaij.c:996); adds sum_i v_i (y_new_i - y_old_i) to the value of the live ticket t */
-int phip_mat_multadd_dot(phip_mat A, const double *d_x, double *d_y, const double *d_v, const phip_ticket *t);
+/* y += A x in place (phip_mat_multadd with z == y, mpiaij.c:996); adds sum_i v_i (y_new_i - y_old_i) to the value of the live ticket t;
+ * publish != 0 also delivers the accumulated value to the ticket's host slot (phip_ticket_wait), for a ticket opened without publish */
+int phip_mat_multadd_dot(phip_mat A, const double *d_x, double *d_y, const double *d_v, int publish, const phip_ticket *t);
 int phip_ticket_values(phip_ctx ctx, const phip_ticket *t, double **d_vals);
 int phip_ticket_wait(phip_ctx ctx, const phip_ticket *t, double *h_vals);
 
@@ -193,6 +197,13 @@ int phip_comm_destroy(phip_comm comm);
 int phip_comm_rank_size(phip_comm comm, int *rank, int *size);
 /* in-place all-reduce of n doubles in device memory, op 0 = SUM, 1 = MAX; stream-ordered on the context's stream */
 int phip_comm_allreduce(phip_comm comm, double *d_buf, int32_t n, int op);
+/* The MPI_Allreduce of VecDot_MPI / VecNorm_MPI / VecMDot_MPI (pbvec.c:9-19, pvec2.c:10-85) on HOST values: op 0 SUM, 1 MAX (NaN
+ * propagates), n <= PHIP_MAX_MVEC, combined in rank order on every rank (identical bits everywhere).  Ranks of one node ("rccl",
+ * "shm", "threads" backends) meet in a shared-memory ring -- no kernel, no RCCL call, about a microsecond; ranks on several nodes
+ * fall back to ncclAllReduce through a device staging buffer; the callbacks backend uses the application's all-gather.
+ * backend "shm" (phip_comm_create): processes of one node joined by that ring alone (id128 = any 128-byte key the ranks share);
+ * it offers this call, phip_comm_allgather_host and phip_comm_barrier, and carries no device traffic. */
+int phip_comm_allreduce_host(phip_comm comm, double *h_vals, int32_t n, int op);
 /* host-side collectives used at set-up (the PetscGatherNumberOfMessages/MessageLengths + Isend/Irecv handshake of
  * VecScatterCreate_PtoS, vpscat.c:2346-2392): all-gather of fixed-size records and variable all-to-all of int32 lists */
 int phip_comm_allgather_host(phip_comm comm, const void *h_send, void *h_recv, size_t bytes_per_rank);

@@ -72,6 +72,8 @@ PetscErrorCode PetscHipInitializeWithCallbacks(int device, int nranks, int rank,
 PetscErrorCode PetscHipFinalize(PetscComm *world);
 /* by-product reductions (include/petschip.h "by-product reductions"): on by default; PETSC_FALSE makes every VecDot/VecNorm a kernel of its own */
 PetscErrorCode PetscHipSetByProducts(PetscComm comm, PetscBool flg);
+/* PETSC_TRUE (default): the ranks' partial dot products / norms meet on the host (shared-memory ring of the node); PETSC_FALSE: ncclAllReduce */
+PetscErrorCode PetscHipSetHostReductions(PetscComm comm, PetscBool flg);
 PetscErrorCode PetscCommGetSelf(PetscComm world, PetscComm *self);     /* PETSC_COMM_SELF */
 PetscErrorCode PetscCommRankSize(PetscComm comm, int *rank, int *size); /* MPI_Comm_rank / MPI_Comm_size */
 PetscErrorCode PetscCommGetContext(PetscComm comm, phip_ctx *ctx);

@@ -699,7 +699,7 @@ static PetscErrorCode MatMult_MPIAIJHIP(Mat A,Vec xx,Vec yy)   /* mpiaij.c:984-9
   if (square) CHKERRPHIP(phip_mat_mult_dot(((Mat_SeqAIJHIP*)a->A->spptr)->dev,x,y,x,0,&t));
   else        CHKERRPHIP(phip_mat_mult(((Mat_SeqAIJHIP*)a->A->spptr)->dev,x,y));    /* diagonal block overlaps the exchange */
   CHKERRPHIP(phip_halo_end(h->halo));
-  if (square) CHKERRPHIP(phip_mat_multadd_dot(((Mat_SeqAIJHIP*)a->B->spptr)->dev,l,y,x,&t));
+  if (square) CHKERRPHIP(phip_mat_multadd_dot(((Mat_SeqAIJHIP*)a->B->spptr)->dev,l,y,x,1,&t));
   else        CHKERRPHIP(phip_mat_multadd(((Mat_SeqAIJHIP*)a->B->spptr)->dev,l,y,y));
   VEC_DONE(a->lvec,l); VEC_DONE(yy,y);
   if (square) { ierr = VecHIPByProductRecord(yy,2,&t,xx,NULL);CHKERRQ(ierr); }

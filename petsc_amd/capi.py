@@ -65,11 +65,12 @@ SIGNATURES = [
     ("phip_vec_reciprocal", C.c_int, [_vp, C.c_int32, _vp]),
     ("phip_vec_pointwise_mult_reduce", C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, C.c_int, _vp]),
     ("phip_mat_mult_dot", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
-    ("phip_mat_multadd_dot", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    ("phip_mat_multadd_dot", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
     ("phip_ticket_values", C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     ("phip_ticket_wait", C.c_int, [_vp, _vp, _pD]),
     ("phip_jacobi_setup", C.c_int, [_vp, C.c_int32, _vp, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     ("phip_vec_reduce_local", C.c_int, [_vp, C.c_int, C.c_int32, _vp, C.c_int32, C.POINTER(_vp), _vp]),
+    ("phip_vec_reduce_local_host", C.c_int, [_vp, C.c_int, C.c_int32, _vp, C.c_int32, C.POINTER(_vp), _pD]),
     ("phip_read_scalars", C.c_int, [_vp, _vp, C.c_int32, _pD]),
     ("phip_comm_create_callbacks", C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.POINTER(_vp)]),
     ("phip_comm_unique_id", C.c_int, [_vp]),
@@ -77,6 +78,7 @@ SIGNATURES = [
     ("phip_comm_destroy", C.c_int, [_vp]),
     ("phip_comm_rank_size", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("phip_comm_allreduce", C.c_int, [_vp, _vp, C.c_int32, C.c_int]),
+    ("phip_comm_allreduce_host", C.c_int, [_vp, _pD, C.c_int32, C.c_int]),
     ("phip_comm_allgather_host", C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     ("phip_comm_alltoallv_i32", C.c_int, [_vp, _pI, _pI, _pI, _pI]),
     ("phip_comm_barrier", C.c_int, [_vp]),
@@ -91,6 +93,11 @@ SIGNATURES = [
 
 class Ticket(C.Structure):
     _fields_ = [("slot", C.c_int32), ("nvals", C.c_int32), ("seq", C.c_uint64)]
+
+
+def last_error():
+    """Text of the calling thread's last libpetschip error."""
+    return load().phip_last_error().decode()
 
 
 class PhipError(RuntimeError):

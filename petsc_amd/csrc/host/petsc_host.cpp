@@ -58,6 +58,7 @@ struct _p_PetscComm {
   _p_PetscComm *self;
   /* by-product reductions (include/petschip.h): kind 1 = VecPointwiseMult, kind 2 = MatMult.  A kind switches itself off after 8
      productions in a row that nobody consumed (GMRES never asks for them) and on again when a request comes that it would have served */
+  bool      host_reduce; /* distributed reductions combine on the host (phip_comm_allreduce_host) instead of ncclAllReduce on the device */
   bool      bp_allowed;
   bool      bp_on[3];
   int       bp_streak[3];
@@ -81,7 +82,18 @@ extern "C" PetscErrorCode PetscHipInitialize(int device, const char *backend, co
   s->self = s; w->self = s;
   w->root = w; s->root = w;
   w->bp_allowed = true; w->bp_on[1] = w->bp_on[2] = true;
+  w->host_reduce = !(getenv("PETSCHIP_DEVICE_ALLREDUCE") && atoi(getenv("PETSCHIP_DEVICE_ALLREDUCE")));
   *world = w;
+  return 0;
+}
+
+/* Where the ranks' partial results of VecDot/VecNorm/VecMDot (and of the by-products) meet: PETSC_TRUE (default) on the host, through
+   the node's shared-memory ring (include/petschip.h, phip_comm_allreduce_host); PETSC_FALSE on the device (ncclAllReduce, then one
+   read).  Collective: every rank must make the same choice. */
+extern "C" PetscErrorCode PetscHipSetHostReductions(PetscComm comm, PetscBool flg)
+{
+  if (!comm) SETERRQ(PETSC_ERR_ARG_NULL, "PetscHipSetHostReductions: null communicator");
+  BP(comm)->host_reduce = flg != 0;
   return 0;
 }
 
@@ -112,6 +124,7 @@ extern "C" PetscErrorCode PetscHipInitializeWithCallbacks(int device, int nranks
   s->self = s; w->self = s;
   w->root = w; s->root = w;
   w->bp_allowed = false; /* set-up-only communicator: no device traffic, no by-products */
+  w->host_reduce = true; /* reductions through the application's all-gather */
   *world = w;
   return 0;
 }
@@ -304,6 +317,9 @@ static bool bp_fetch(Vec w)
   const int n = w->bp.ticket.nvals;
   if (w->comm->size == 1) {
     if (phip_ticket_wait(VCTX(w), &w->bp.ticket, w->bp.host)) { w->bp.live = false; return false; }
+  } else if (BP(w->comm)->host_reduce) {
+    if (phip_ticket_wait(VCTX(w), &w->bp.ticket, w->bp.host)) { w->bp.live = false; return false; } /* expired identically on every rank */
+    if (phip_comm_allreduce_host(w->comm->comm, w->bp.host, n, 0)) { w->bp.live = false; return false; }
   } else {
     double *d;
     if (phip_ticket_values(VCTX(w), &w->bp.ticket, &d)) { w->bp.live = false; return false; } /* expired identically on every rank */
@@ -359,52 +375,48 @@ static PetscErrorCode VecMDot_SeqHIP(Vec x, PetscInt nv, const Vec y[], PetscSca
   CHKPHIP(phip_vec_mdot(VCTX(x), x->n, x->d, nv, p.data(), z));
   return 0;
 }
-/* VecDot_MPI pbvec.c:9-19: local dot, MPI_Allreduce(SUM) -> here the local result stays on the device for RCCL */
+/* The reductions of the MPI type: local kernel, then the ranks' values are combined (VecDot_MPI pbvec.c:9-19, VecMDot_MPI pvec2.c:10-25,
+   VecNorm_MPI pvec2.c:49-85).  Host route: the local kernel publishes to pinned memory and the ranks meet in the node's shared-memory
+   ring.  Device route: the local result stays on the device, ncclAllReduce, one read.  kind as in phip_vec_reduce_local. */
+static PetscErrorCode mpi_reduce(Vec x, int kind, PetscInt nv, const double *const *p, int nres, int op, double *r)
+{
+  PetscComm cm = x->comm;
+  if (BP(cm)->host_reduce) {
+    CHKPHIP(phip_vec_reduce_local_host(VCTX(x), kind, x->n, x->d, nv, p, r));
+    CHKPHIP(phip_comm_allreduce_host(cm->comm, r, nres, op));
+  } else {
+    CHKPHIP(phip_vec_reduce_local(VCTX(x), kind, x->n, x->d, nv, p, cm->d_red));
+    CHKPHIP(phip_comm_allreduce(cm->comm, cm->d_red, nres, op));
+    CHKPHIP(phip_read_scalars(VCTX(x), cm->d_red, nres, r));
+  }
+  return 0;
+}
 static PetscErrorCode VecDot_MPIHIP(Vec x, Vec y, PetscScalar *z)
 {
   const double *p[1] = {y->d};
-  CHKPHIP(phip_vec_reduce_local(VCTX(x), 0, x->n, x->d, 1, p, x->comm->d_red));
-  CHKPHIP(phip_comm_allreduce(x->comm->comm, x->comm->d_red, 1, 0));
-  CHKPHIP(phip_read_scalars(VCTX(x), x->comm->d_red, 1, z));
-  return 0;
+  return mpi_reduce(x, 0, 1, p, 1, 0, z);
 }
-/* VecMDot_MPI pvec2.c:10-25: one all-reduce of nv scalars */
+/* one all-reduce of nv scalars */
 static PetscErrorCode VecMDot_MPIHIP(Vec x, PetscInt nv, const Vec y[], PetscScalar *z)
 {
   if (nv > PHIP_MAX_MVEC) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "VecMDot: nv=%d exceeds %d", nv, PHIP_MAX_MVEC);
   std::vector<const double *> p((size_t)nv);
   for (PetscInt k = 0; k < nv; k++) p[(size_t)k] = y[k]->d;
-  CHKPHIP(phip_vec_reduce_local(VCTX(x), 0, x->n, x->d, nv, p.data(), x->comm->d_red));
-  CHKPHIP(phip_comm_allreduce(x->comm->comm, x->comm->d_red, nv, 0));
-  CHKPHIP(phip_read_scalars(VCTX(x), x->comm->d_red, nv, z));
-  return 0;
+  return mpi_reduce(x, 0, nv, p.data(), nv, 0, z);
 }
-/* VecNorm_MPI pvec2.c:49-85 */
 static PetscErrorCode VecNorm_MPIHIP(Vec x, NormType t, PetscReal *z)
 {
-  double *dr = x->comm->d_red;
-  double  r[2];
+  double         r[2];
+  PetscErrorCode ierr;
   switch (t) {
   case NORM_2: case NORM_FROBENIUS:
-    CHKPHIP(phip_vec_reduce_local(VCTX(x), 1, x->n, x->d, 1, NULL, dr));
-    CHKPHIP(phip_comm_allreduce(x->comm->comm, dr, 1, 0));
-    CHKPHIP(phip_read_scalars(VCTX(x), dr, 1, r));
+    ierr = mpi_reduce(x, 1, 1, NULL, 1, 0, r); CHKERRQ(ierr);
     *z = sqrt(r[0]);
     return 0;
-  case NORM_1:
-    CHKPHIP(phip_vec_reduce_local(VCTX(x), 2, x->n, x->d, 1, NULL, dr));
-    CHKPHIP(phip_comm_allreduce(x->comm->comm, dr, 1, 0));
-    CHKPHIP(phip_read_scalars(VCTX(x), dr, 1, z));
-    return 0;
-  case NORM_INFINITY:
-    CHKPHIP(phip_vec_reduce_local(VCTX(x), 3, x->n, x->d, 1, NULL, dr));
-    CHKPHIP(phip_comm_allreduce(x->comm->comm, dr, 1, 1));
-    CHKPHIP(phip_read_scalars(VCTX(x), dr, 1, z));
-    return 0;
+  case NORM_1: return mpi_reduce(x, 2, 1, NULL, 1, 0, z);
+  case NORM_INFINITY: return mpi_reduce(x, 3, 1, NULL, 1, 1, z);
   case NORM_1_AND_2:
-    CHKPHIP(phip_vec_reduce_local(VCTX(x), 4, x->n, x->d, 1, NULL, dr));
-    CHKPHIP(phip_comm_allreduce(x->comm->comm, dr, 2, 0));
-    CHKPHIP(phip_read_scalars(VCTX(x), dr, 2, r));
+    ierr = mpi_reduce(x, 4, 1, NULL, 2, 0, r); CHKERRQ(ierr);
     z[0] = r[0]; z[1] = sqrt(r[1]);
     return 0;
   }
@@ -432,7 +444,7 @@ static PetscErrorCode VecPointwiseMult_HIP(Vec w, Vec x, Vec y)
     const bool want = bp_want(w, 1);
     if (want) {
       phip_ticket t;
-      CHKPHIP(phip_vec_pointwise_mult_reduce(VCTX(w), w->n, w->d, x->d, y->d, w->comm->size == 1, &t));
+      CHKPHIP(phip_vec_pointwise_mult_reduce(VCTX(w), w->n, w->d, x->d, y->d, w->comm->size == 1 || BP(w->comm)->host_reduce, &t));
       bp_record(w, 1, true, &t, x, y);
       return 0;
     }
@@ -1322,7 +1334,7 @@ static PetscErrorCode MatMult_MPIAIJHIP(Mat A, Vec x, Vec y)
   if (want) CHKPHIP(phip_mat_mult_dot(A->A.dev, x->d, y->d, x->d, 0, &t)); /* local sum x_i (A_d x)_i ... */
   else CHKPHIP(phip_mat_mult(A->A.dev, x->d, y->d));
   CHKPHIP(phip_halo_end(A->halo));
-  if (want) CHKPHIP(phip_mat_multadd_dot(A->B.dev, A->lvec, y->d, x->d, &t)); /* ... + sum x_i (B lvec)_i */
+  if (want) CHKPHIP(phip_mat_multadd_dot(A->B.dev, A->lvec, y->d, x->d, BP(A->comm)->host_reduce ? 1 : 0, &t)); /* ... + sum x_i (B lvec)_i */
   else CHKPHIP(phip_mat_multadd(A->B.dev, A->lvec, y->d, y->d));
   if (square) bp_record(y, 2, want, want ? &t : NULL, x, NULL);
   return 0;

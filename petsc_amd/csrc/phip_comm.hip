@@ -5,14 +5,27 @@
 //                   ncclSend/ncclRecv per neighbour on the communication stream, received straight into lvec
 //                   (the receive side of MatSetUpMultiply's scatter is contiguous, vpscat.c:2524-2532).
 //                   xGMI is point to point, so neighbour exchanges use one link per peer and never a ring.
+//                   Scalars that the host needs (dot products, norms) do NOT go through RCCL: every rank's kernel publishes its local
+//                   result to pinned host memory, and the ranks of a node combine them through a shared-memory ring
+//                   (phip_comm_allreduce_host below): a few hundred nanoseconds per rank instead of a collective kernel launch.
+// backend "shm"     the host side of "rccl" alone: ranks are processes of one node joined by the shared-memory ring (host all-reduce,
+//                   all-gather, barrier); no device traffic.  Used by the CPU tests of that ring.
 // backend "self"    size 1.
 // backend "threads" the ranks are host threads of one process that share one GPU; collectives rendezvous through a
 //                   process-wide table.  It exists so that the distributed code path (plan handshake, pack kernel, lvec
 //                   offsets, overlap ordering) can be exercised on a single-GPU box; it is not a performance path.
 #include "phip_internal.h"
 #include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <string.h>
 #include <rccl/rccl.h>
 #include <stdlib.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 #include <algorithm>
 #include <condition_variable>
 #include <map>
@@ -80,6 +93,7 @@ struct ThreadGroup {
   long                    generation = 0;
   std::vector<const void *> slot_a, slot_b;
   int                     refs = 0;
+  void                   *hr_mem = NULL; /* host reduction ring shared by the threads of the group */
   void barrier()
   {
     std::unique_lock<std::mutex> lk(m);
@@ -91,7 +105,29 @@ struct ThreadGroup {
 static std::map<uint64_t, ThreadGroup *> g_groups;
 static std::mutex                        g_groups_mutex;
 
-enum { BACKEND_SELF = 0, BACKEND_RCCL = 1, BACKEND_THREADS = 2, BACKEND_CALLBACKS = 3 };
+enum { BACKEND_SELF = 0, BACKEND_RCCL = 1, BACKEND_THREADS = 2, BACKEND_CALLBACKS = 3, BACKEND_SHM = 4 };
+
+/* ---- host reduction ring ---------------------------------------------------------------------------------------------
+   HR_ROUNDS x size slots in memory every rank of the node can address (POSIX shared memory between processes, the heap between the
+   threads of the "threads" backend).  Round s: rank r fills slot[s % HR_ROUNDS][r] and release-stores s into its sequence word, then
+   reads the slots of all ranks as their sequence words reach s, always in rank order -- every rank computes the same bits.
+   A slot is reused HR_ROUNDS rounds later; a rank can be at most one round ahead of the slowest reader (it cannot finish round s+1
+   before every rank has written round s+1, i.e. finished reading round s), so two rounds of slots would already be enough. */
+#define HR_ROUNDS 4
+#define HR_PAYLOAD (sizeof(double) * PHIP_MAX_MVEC)
+struct alignas(64) HostRingSlot {
+  uint64_t seq;
+  uint64_t pad[7];
+  unsigned char payload[HR_PAYLOAD];
+};
+struct HostRing {
+  HostRingSlot *slots;
+  size_t        bytes;
+  uint64_t      round;
+  int           is_shm;
+  char          name[48];
+};
+static size_t hr_bytes(int size) { return sizeof(HostRingSlot) * HR_ROUNDS * (size_t)size; }
 
 struct phip_comm_s {
   phip_allgather_fn     cb_allgather;
@@ -102,6 +138,8 @@ struct phip_comm_s {
   ncclComm_t   nccl;
   ThreadGroup *tg;
   uint64_t     tg_key;
+  HostRing     hr;       /* hr.slots == NULL: no ring (ranks on several nodes) -> phip_comm_allreduce_host stages through the device */
+  double      *d_stage;  /* device scratch of that fallback */
 };
 
 struct phip_halo_s {
@@ -119,6 +157,103 @@ struct phip_halo_s {
   int32_t  *d_tgt, *d_tptr, *d_tpos;
   const double *rev_lvec;
 };
+
+/* ---- host reduction ring: attach / detach / one round -------------------------------------------------------------------- */
+#define HR_MAGIC 0x70686970686f7374ull /* "phiphost" */
+#define HR_HEADER 64
+static double hr_now(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static double hr_timeout(void)
+{
+  static const double t = getenv("PHIP_HOST_RING_TIMEOUT") ? atof(getenv("PHIP_HOST_RING_TIMEOUT")) : 120.0;
+  return t;
+}
+/* wait until *p == want (acquire); fails after hr_timeout() seconds: a peer died or never joined */
+static int hr_wait(const uint64_t *p, uint64_t want, const char *what, int peer)
+{
+  double t0 = 0.0;
+  for (unsigned long spin = 1;; spin++) {
+    if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == want) return 0;
+    __builtin_ia32_pause();
+    if ((spin & 0xFFFF) == 0) {
+      const double now = hr_now();
+      if (t0 == 0.0) t0 = now;
+      else if (now - t0 > hr_timeout()) {
+        phip_set_error("%s: rank %d did not arrive within %.0f s", what, peer, hr_timeout());
+        return PHIP_ERR_LIB;
+      }
+      if ((spin & 0xFFFFFF) == 0) sched_yield();
+    }
+  }
+}
+static uint64_t hr_hash(const void *id128, int nranks)
+{
+  uint64_t h = 1469598103934665603ull;
+  for (int i = 0; i < 128; i++) { h ^= ((const unsigned char *)id128)[i]; h *= 1099511628211ull; }
+  h ^= (uint64_t)nranks; h *= 1099511628211ull;
+  return h;
+}
+/* processes of one node: rank 0 creates the segment, the others open it once it exists; the name dies after the first round */
+static int hr_attach_shm(phip_comm c, const void *id128)
+{
+  HostRing *r = &c->hr;
+  r->bytes = HR_HEADER + hr_bytes(c->size);
+  snprintf(r->name, sizeof(r->name), "/phip_%016llx", (unsigned long long)hr_hash(id128, c->size));
+  int fd = -1;
+  if (c->rank == 0) {
+    shm_unlink(r->name); /* a leftover of a run that died under the same key */
+    fd = shm_open(r->name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    PHIP_REQUIRE(fd >= 0, PHIP_ERR_LIB, "phip_comm_create: shm_open(%s) failed: %s", r->name, strerror(errno));
+    if (ftruncate(fd, (off_t)r->bytes)) { close(fd); shm_unlink(r->name); PHIP_REQUIRE(0, PHIP_ERR_LIB, "phip_comm_create: ftruncate(%s): %s", r->name, strerror(errno)); }
+  } else {
+    const double t0 = hr_now();
+    for (;;) {
+      fd = shm_open(r->name, O_RDWR, 0600);
+      if (fd >= 0) {
+        struct stat st;
+        if (!fstat(fd, &st) && (size_t)st.st_size == r->bytes) break;
+        close(fd); fd = -1;
+      }
+      PHIP_REQUIRE(hr_now() - t0 < hr_timeout(), PHIP_ERR_LIB, "phip_comm_create: rank 0 never created %s (ranks on different nodes?)", r->name);
+      usleep(200);
+    }
+  }
+  void *mem = mmap(NULL, r->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (mem == MAP_FAILED) { if (c->rank == 0) shm_unlink(r->name); PHIP_REQUIRE(0, PHIP_ERR_LIB, "phip_comm_create: mmap(%s): %s", r->name, strerror(errno)); }
+  r->slots = (HostRingSlot *)((char *)mem + HR_HEADER);
+  r->is_shm = 1; r->round = 0;
+  if (c->rank == 0) __atomic_store_n((uint64_t *)mem, HR_MAGIC, __ATOMIC_RELEASE); /* a fresh segment is zero-filled */
+  else {
+    int rc = hr_wait((const uint64_t *)mem, HR_MAGIC, "phip_comm_create", 0);
+    if (rc) return rc;
+  }
+  return 0;
+}
+static void hr_detach(phip_comm c)
+{
+  if (c->hr.slots && c->hr.is_shm) munmap((char *)c->hr.slots - HR_HEADER, c->hr.bytes);
+  c->hr.slots = NULL;
+}
+/* one round: every rank contributes `bytes` (<= HR_PAYLOAD); on return peers[p] points at rank p's contribution, valid until this
+   rank's next round but one */
+static int hr_round(phip_comm c, const void *mine, size_t bytes, const unsigned char **peers)
+{
+  HostRing      *r = &c->hr;
+  const uint64_t s = ++r->round;
+  HostRingSlot  *row = r->slots + (size_t)(s % HR_ROUNDS) * (size_t)c->size;
+  memcpy(row[c->rank].payload, mine, bytes);
+  __atomic_store_n(&row[c->rank].seq, s, __ATOMIC_RELEASE);
+  for (int p = 0; p < c->size; p++) {
+    if (p != c->rank) { int rc = hr_wait(&row[p].seq, s, "host ring", p); if (rc) return rc; }
+    peers[p] = row[p].payload;
+  }
+  return 0;
+}
 
 extern "C" int phip_comm_unique_id(void *id128)
 {
@@ -138,6 +273,7 @@ extern "C" int phip_comm_create(phip_ctx ctx, const char *backend, const void *i
   PHIP_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: rank %d of %d", rank, nranks);
   phip_comm c = new phip_comm_s();
   c->ctx = ctx; c->rank = rank; c->size = nranks; c->nccl = NULL; c->tg = NULL; c->tg_key = 0;
+  memset(&c->hr, 0, sizeof(c->hr)); c->d_stage = NULL;
   if (!strcmp(backend, "self")) {
     PHIP_REQUIRE(nranks == 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: backend self needs nranks 1");
     c->backend = BACKEND_SELF;
@@ -151,16 +287,53 @@ extern "C" int phip_comm_create(phip_ctx ctx, const char *backend, const void *i
     PHIP_CHECK_HIP(hipSetDevice(ctx->device));
     PHIP_CHECK_NCCL(g_rccl.CommInitRank(&c->nccl, nranks, id, rank));
     c->backend = BACKEND_RCCL;
+    PHIP_CHECK_HIP(hipMalloc((void **)&c->d_stage, sizeof(double) * PHIP_MAX_MVEC));
+    if (nranks > 1) {
+      /* the host ring needs every rank on one node: compare host names (PHIP_HOST_RING=0 forces the device path) */
+      char     host[256] = {0};
+      gethostname(host, sizeof(host) - 1);
+      uint64_t mine = 1469598103934665603ull;
+      for (size_t i = 0; i < sizeof(host); i++) { mine ^= (unsigned char)host[i]; mine *= 1099511628211ull; }
+      if (getenv("PHIP_HOST_RING") && !atoi(getenv("PHIP_HOST_RING"))) mine ^= (uint64_t)rank + 1; /* pretend the ranks are apart */
+      std::vector<uint64_t> all((size_t)nranks);
+      if ((rc = phip_comm_allgather_host(c, &mine, all.data(), sizeof(uint64_t)))) return rc;
+      bool same = true;
+      for (int p = 0; p < nranks; p++) same = same && all[(size_t)p] == all[0];
+      if (same) {
+        if ((rc = hr_attach_shm(c, id128))) return rc;
+        const unsigned char *peers[1024];
+        PHIP_REQUIRE(nranks <= 1024, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: %d ranks on one node", nranks);
+        if ((rc = hr_round(c, &mine, sizeof(mine), peers))) { if (rank == 0) shm_unlink(c->hr.name); return rc; } /* everyone has mapped the segment: its name can go */
+        if (rank == 0) shm_unlink(c->hr.name);
+      }
+    }
+  } else if (!strcmp(backend, "shm")) {
+    PHIP_REQUIRE(id128, PHIP_ERR_ARG_NULL, "phip_comm_create: shm backend needs a 128-byte key shared by the ranks");
+    PHIP_REQUIRE(nranks <= 1024, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: %d ranks on one node", nranks);
+    c->backend = BACKEND_SHM;
+    if (nranks > 1) {
+      int rc = hr_attach_shm(c, id128);
+      if (rc) return rc;
+      const unsigned char *peers[1024];
+      uint64_t             one = 1;
+      if ((rc = hr_round(c, &one, sizeof(one), peers))) { if (rank == 0) shm_unlink(c->hr.name); return rc; }
+      if (rank == 0) shm_unlink(c->hr.name);
+    }
   } else if (!strcmp(backend, "threads")) {
     PHIP_REQUIRE(id128, PHIP_ERR_ARG_NULL, "phip_comm_create: threads backend needs a group key");
     memcpy(&c->tg_key, id128, sizeof(uint64_t));
     {
       std::lock_guard<std::mutex> lk(g_groups_mutex);
       ThreadGroup *&g = g_groups[c->tg_key];
-      if (!g) { g = new ThreadGroup(); g->n = nranks; g->slot_a.resize((size_t)nranks); g->slot_b.resize((size_t)nranks); }
+      if (!g) {
+        g = new ThreadGroup(); g->n = nranks; g->slot_a.resize((size_t)nranks); g->slot_b.resize((size_t)nranks);
+        g->hr_mem = aligned_alloc(64, hr_bytes(nranks));
+        memset(g->hr_mem, 0, hr_bytes(nranks));
+      }
       PHIP_REQUIRE(g->n == nranks, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: thread group size mismatch");
       g->refs++;
       c->tg = g;
+      c->hr.slots = (HostRingSlot *)g->hr_mem; c->hr.bytes = hr_bytes(nranks); c->hr.round = 0; c->hr.is_shm = 0;
     }
     c->backend = BACKEND_THREADS;
   } else {
@@ -178,6 +351,7 @@ extern "C" int phip_comm_create_callbacks(phip_ctx ctx, int nranks, int rank, ph
   PHIP_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create_callbacks: rank %d of %d", rank, nranks);
   phip_comm c = new phip_comm_s();
   c->ctx = ctx; c->rank = rank; c->size = nranks; c->nccl = NULL; c->tg = NULL; c->tg_key = 0;
+  memset(&c->hr, 0, sizeof(c->hr)); c->d_stage = NULL;
   c->backend = BACKEND_CALLBACKS; c->cb_allgather = allgather; c->cb_alltoallv = alltoallv; c->cb_user = user;
   *out = c;
   return 0;
@@ -191,10 +365,12 @@ extern "C" int phip_comm_destroy(phip_comm c)
     hipStreamSynchronize(c->ctx->stream);
     hipStreamSynchronize(c->ctx->comm_stream);
     g_rccl.CommDestroy(c->nccl);
+    hipFree(c->d_stage);
   }
+  hr_detach(c);
   if (c->backend == BACKEND_THREADS) {
     std::lock_guard<std::mutex> lk(g_groups_mutex);
-    if (--c->tg->refs == 0) { g_groups.erase(c->tg_key); delete c->tg; }
+    if (--c->tg->refs == 0) { g_groups.erase(c->tg_key); free(c->tg->hr_mem); delete c->tg; }
   }
   delete c;
   return 0;
@@ -212,7 +388,7 @@ extern "C" int phip_comm_barrier(phip_comm c)
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_comm_barrier: null communicator");
   if (c->backend == BACKEND_THREADS) c->tg->barrier();
-  else if (c->backend == BACKEND_RCCL || c->backend == BACKEND_CALLBACKS) {
+  else if (c->backend == BACKEND_RCCL || c->backend == BACKEND_CALLBACKS || c->backend == BACKEND_SHM) {
     int32_t one = 1;
     std::vector<int32_t> all((size_t)c->size);
     return phip_comm_allgather_host(c, &one, all.data(), sizeof(int32_t));
@@ -227,7 +403,7 @@ extern "C" int phip_comm_allreduce(phip_comm c, double *d_buf, int32_t n, int op
   PHIP_REQUIRE(op == 0 || op == 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_allreduce: op %d", op);
   if (c->size == 1 || n == 0) return 0;
   PHIP_NEED_DEVICE(c->ctx, "phip_comm_allreduce");
-  PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS, PHIP_ERR_SUP, "phip_comm_allreduce: the callbacks backend carries set-up traffic only");
+  PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS && c->backend != BACKEND_SHM, PHIP_ERR_SUP, "phip_comm_allreduce: this backend carries no device traffic");
   if (c->backend == BACKEND_RCCL) {
     PHIP_CHECK_NCCL(g_rccl.AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->nccl, c->ctx->stream));
     return 0;
@@ -251,10 +427,63 @@ extern "C" int phip_comm_allreduce(phip_comm c, double *d_buf, int32_t n, int op
   return 0;
 }
 
+/* All-reduce of n host doubles (op 0 SUM, 1 MAX with NaN propagation): the MPI_Allreduce of VecDot_MPI / VecNorm_MPI / VecMDot_MPI
+   (pbvec.c:9-19, pvec2.c:10-85).  The local kernels publish their results to pinned host memory anyway (the unmodified KSP consumes
+   every reduction on the host), so the cross-rank step stays on the host: one round of the shared-memory ring, combined in rank
+   order on every rank (bit-identical results everywhere).  Ranks on several nodes: staged through the device and ncclAllReduce. */
+extern "C" int phip_comm_allreduce_host(phip_comm c, double *h_vals, int32_t n, int op)
+{
+  PHIP_REQUIRE(c && (h_vals || !n), PHIP_ERR_ARG_NULL, "phip_comm_allreduce_host: null argument");
+  PHIP_REQUIRE(n >= 0 && n <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_allreduce_host: n=%d", n);
+  PHIP_REQUIRE(op == 0 || op == 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_allreduce_host: op %d", op);
+  if (c->size == 1 || n == 0) return 0;
+  std::vector<double>  gathered;
+  const unsigned char *peers[1024];
+  if (c->hr.slots) {
+    int rc = hr_round(c, h_vals, sizeof(double) * (size_t)n, peers);
+    if (rc) return rc;
+  } else if (c->backend == BACKEND_CALLBACKS) {
+    gathered.resize((size_t)n * (size_t)c->size);
+    int rc = c->cb_allgather(c->cb_user, h_vals, gathered.data(), sizeof(double) * (size_t)n);
+    PHIP_REQUIRE(rc == 0, PHIP_ERR_LIB, "phip_comm_allreduce_host: the application's all-gather callback failed with %d", rc);
+    PHIP_REQUIRE(c->size <= 1024, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_allreduce_host: %d ranks", c->size);
+    for (int p = 0; p < c->size; p++) peers[p] = (const unsigned char *)(gathered.data() + (size_t)p * (size_t)n);
+  } else {
+    PHIP_REQUIRE(c->backend == BACKEND_RCCL, PHIP_ERR_SUP, "phip_comm_allreduce_host: this communicator has no host ring");
+    PHIP_CHECK_HIP(hipMemcpyAsync(c->d_stage, h_vals, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->ctx->stream));
+    PHIP_CHECK_NCCL(g_rccl.AllReduce(c->d_stage, c->d_stage, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->nccl, c->ctx->stream));
+    PHIP_CHECK_HIP(hipMemcpyAsync(h_vals, c->d_stage, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->ctx->stream));
+    PHIP_CHECK_HIP(hipStreamSynchronize(c->ctx->stream));
+    return 0;
+  }
+  double acc[PHIP_MAX_MVEC];
+  for (int p = 0; p < c->size; p++) {
+    double tmp[PHIP_MAX_MVEC];
+    memcpy(tmp, peers[p], sizeof(double) * (size_t)n);
+    for (int i = 0; i < n; i++) {
+      if (p == 0) acc[i] = tmp[i];
+      else if (op == 0) acc[i] += tmp[i];
+      else acc[i] = (tmp[i] != tmp[i] || tmp[i] > acc[i]) ? tmp[i] : acc[i];
+    }
+  }
+  memcpy(h_vals, acc, sizeof(double) * (size_t)n);
+  return 0;
+}
+
 extern "C" int phip_comm_allgather_host(phip_comm c, const void *h_send, void *h_recv, size_t bytes)
 {
   PHIP_REQUIRE(c && h_send && h_recv, PHIP_ERR_ARG_NULL, "phip_comm_allgather_host: null argument");
-  if (c->backend == BACKEND_SELF) { memcpy(h_recv, h_send, bytes); return 0; }
+  if (c->backend == BACKEND_SELF || c->size == 1) { memcpy(h_recv, h_send, bytes); return 0; }
+  if (c->backend == BACKEND_SHM) { /* through the ring, HR_PAYLOAD bytes per rank and round */
+    const unsigned char *peers[1024];
+    for (size_t off = 0; off < bytes; off += HR_PAYLOAD) {
+      const size_t chunk = bytes - off < HR_PAYLOAD ? bytes - off : HR_PAYLOAD;
+      int          rc = hr_round(c, (const char *)h_send + off, chunk, peers);
+      if (rc) return rc;
+      for (int p = 0; p < c->size; p++) memcpy((char *)h_recv + (size_t)p * bytes + off, peers[p], chunk);
+    }
+    return 0;
+  }
   if (c->backend == BACKEND_CALLBACKS) {
     int rc = c->cb_allgather(c->cb_user, h_send, h_recv, bytes);
     PHIP_REQUIRE(rc == 0, PHIP_ERR_LIB, "phip_comm_allgather_host: the application's all-gather callback failed with %d", rc);
@@ -291,6 +520,7 @@ extern "C" int phip_comm_alltoallv_i32(phip_comm c, const int32_t *h_send, const
     if (send_counts[0]) memcpy(h_recv, h_send, sizeof(int32_t) * (size_t)send_counts[0]);
     return 0;
   }
+  PHIP_REQUIRE(c->backend != BACKEND_SHM, PHIP_ERR_SUP, "phip_comm_alltoallv_i32: not offered by the shm backend");
   if (c->backend == BACKEND_CALLBACKS) {
     int rc = c->cb_alltoallv(c->cb_user, h_send, send_counts, h_recv, recv_counts);
     PHIP_REQUIRE(rc == 0, PHIP_ERR_LIB, "phip_comm_alltoallv_i32: the application's all-to-all callback failed with %d", rc);
@@ -410,7 +640,7 @@ extern "C" int phip_halo_begin(phip_halo h, const double *d_x_local, double *d_l
   h->lvec = d_lvec;
   if (c->size == 1) return 0;
   PHIP_NEED_DEVICE(ctx, "phip_halo_begin");
-  PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS, PHIP_ERR_SUP, "phip_halo_begin: the callbacks backend carries set-up traffic only");
+  PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS && c->backend != BACKEND_SHM, PHIP_ERR_SUP, "phip_halo_begin: this backend carries no device traffic");
   if (h->nsend) {
     hipLaunchKernelGGL(halo_pack_kernel, dim3(phip_grid_for(h->nsend, 1, 1024)), dim3(PHIP_THREADS), 0, ctx->stream, h->nsend, h->d_to_indices, d_x_local, h->d_sendbuf);
     PHIP_CHECK_HIP(hipGetLastError());
@@ -491,7 +721,7 @@ extern "C" int phip_halo_reverse_begin(phip_halo h, const double *d_lvec)
   h->rev_lvec = d_lvec;
   if (c->size == 1) return 0;
   PHIP_NEED_DEVICE(ctx, "phip_halo_reverse_begin");
-  PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS, PHIP_ERR_SUP, "phip_halo_reverse_begin: the callbacks backend carries set-up traffic only");
+  PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS && c->backend != BACKEND_SHM, PHIP_ERR_SUP, "phip_halo_reverse_begin: this backend carries no device traffic");
   if (c->backend == BACKEND_RCCL) {
     /* lvec is complete once everything queued on the compute stream so far has run; the receive buffer is the forward send buffer
        (one scatter context carries one exchange at a time, vscat.c:1670) */

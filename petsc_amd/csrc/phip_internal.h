@@ -44,7 +44,7 @@ int phip_wait_seq(phip_ctx c, unsigned long long seq);
 struct RedCtl;
 int phip_ticket_open(phip_ctx c, int nvals, int publish, phip_ticket *t, struct RedCtl *ctl);
 /* ... or adds one more contribution to the live ticket t */
-int phip_ticket_accumulate(phip_ctx c, const phip_ticket *t, struct RedCtl *ctl);
+int phip_ticket_accumulate(phip_ctx c, const phip_ticket *t, int publish, struct RedCtl *ctl);
 
 int phip_prof_open(phip_ctx c, int kind, hipEvent_t *start, hipEvent_t *stop);
 

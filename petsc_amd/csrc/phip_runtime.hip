@@ -319,11 +319,12 @@ static int ticket_live(phip_ctx c, const phip_ticket *t)
   return t && t->seq && t->seq <= c->ring_seq && c->ring_seq - t->seq < PHIP_RING && t->slot == (int)(t->seq % PHIP_RING) && t->nvals >= 1 && t->nvals < PHIP_RING_VALS;
 }
 
-int phip_ticket_accumulate(phip_ctx c, const phip_ticket *t, RedCtl *ctl)
+int phip_ticket_accumulate(phip_ctx c, const phip_ticket *t, int publish, RedCtl *ctl)
 {
   PHIP_REQUIRE(ticket_live(c, t), PHIP_ERR_ARG_WRONGSTATE, "phip_ticket_accumulate: the ticket has expired");
   ctl->partial = c->d_partials; ctl->ticket = c->d_ticket; ctl->d_out = c->d_ring + (size_t)t->slot * PHIP_RING_VALS;
   ctl->kofs = 0; ctl->accumulate = 1; ctl->npub = 0; ctl->h_slot = NULL; ctl->h_seq = NULL; ctl->seq = 0;
+  if (publish) { ctl->h_slot = c->h_ring_dev[t->slot].vals; ctl->h_seq = &c->h_ring_dev[t->slot].seq; ctl->seq = t->seq; ctl->npub = t->nvals; }
   return 0;
 }
 

@@ -715,13 +715,13 @@ extern "C" int phip_mat_mult_dot(phip_mat A, const double *d_x, double *d_y, con
   return launch_spmv_dot(A, d_x, NULL, d_y, 0, d_v, ctl);
 }
 
-extern "C" int phip_mat_multadd_dot(phip_mat A, const double *d_x, double *d_y, const double *d_v, const phip_ticket *t)
+extern "C" int phip_mat_multadd_dot(phip_mat A, const double *d_x, double *d_y, const double *d_v, int publish, const phip_ticket *t)
 {
   PHIP_REQUIRE(A && t && ((d_y && d_v) || !A->m) && (d_x || !A->nnz), PHIP_ERR_ARG_NULL, "phip_mat_multadd_dot: null argument");
   PHIP_NEED_DEVICE(A->ctx, "phip_mat_multadd_dot");
   PHIP_REQUIRE(d_x != d_y || !A->m, PHIP_ERR_ARG_SIZ, "phip_mat_multadd_dot: x and y must be different vectors");
   RedCtl ctl;
-  int    rc = phip_ticket_accumulate(A->ctx, t, &ctl);
+  int    rc = phip_ticket_accumulate(A->ctx, t, publish, &ctl);
   if (rc) return rc;
   return launch_spmv_dot(A, d_x, d_y, d_y, 1, d_v, ctl);
 }

@@ -422,6 +422,20 @@ static int reduce_to_host(phip_ctx c, int kind, int32_t n, const double *d_x, in
   return 0;
 }
 
+/* the local part of a distributed reduction, delivered to the HOST (one launch, pinned slot, spin): raw sums, no square root, so that
+   phip_comm_allreduce_host can combine the ranks' values.  kind as in phip_vec_reduce_local. */
+extern "C" int phip_vec_reduce_local_host(phip_ctx c, int kind, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *h_out)
+{
+  CHECK_CTX(c, "phip_vec_reduce_local_host"); CHECK_N(n, "phip_vec_reduce_local_host");
+  PHIP_REQUIRE(h_out, PHIP_ERR_ARG_NULL, "phip_vec_reduce_local_host: null output");
+  PHIP_REQUIRE(kind >= 0 && kind <= 4, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_reduce_local_host: kind %d", kind);
+  if (kind == 0) {
+    PHIP_REQUIRE(nv >= 0 && nv <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_reduce_local_host: nv=%d (max %d)", nv, PHIP_MAX_MVEC);
+    if (nv == 0) return 0;
+  }
+  return reduce_to_host(c, kind, n, d_x, nv, h_dy, kind == 0 ? nv : (kind == 4 ? 2 : 1), h_out);
+}
+
 extern "C" int phip_vec_dot(phip_ctx c, int32_t n, const double *d_x, const double *d_y, double *h_z)
 {
   CHECK_CTX(c, "phip_vec_dot"); CHECK_N(n, "phip_vec_dot");

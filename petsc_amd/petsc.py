@@ -188,6 +188,9 @@ class Comm:
     def set_byproducts(self, flg):
         chk(lib().PetscHipSetByProducts(self.h, 1 if flg else 0))
 
+    def set_host_reductions(self, flg):
+        chk(lib().PetscHipSetHostReductions(self.h, 1 if flg else 0))
+
     def finalize(self):
         if self.h:
             chk(lib().PetscHipFinalize(C.byref(self.h)))

@@ -326,6 +326,39 @@ def test_cg_jacobi_parity(orc, golden_dir, size):
         check_ksp(run_ranks(size, lambda comm: ksp_case(comm, ai, aj, aa, b, "cg", **opts)), ref)
 
 
+@pytest.mark.parametrize("size", [2, 3])
+def test_reductions_device_route(orc, size):
+    """The ranks' partial results can meet on the host (default: shared-memory ring, phip_comm_allreduce_host) or on the device
+    (ncclAllReduce; PetscHipSetHostReductions(comm, PETSC_FALSE)).  Both routes: same CG / GMRES histories, same reductions."""
+    from petsc_amd import generators as G, petsc as P
+    ai, aj, aa = G.convdiff3d_7pt(11, 9, 8)
+    n = len(ai) - 1
+    b = orc.operator(ai, aj, aa, 1).mult(np.ones(n))
+    sym = G.laplace3d_7pt(12, dirichlet_rows=False)
+    bs = orc.operator(*sym, 1).mult(np.ones(len(sym[0]) - 1))
+
+    def body(comm, host):
+        comm.set_host_reductions(host)
+        out = [ksp_case(comm, ai, aj, aa, b, "gmres", rtol=1e-9), ksp_case(comm, *sym, bs, "cg", rtol=1e-9)]
+        rs, re = local_slice(comm, n)
+        x = P.Vec.from_array(comm, np.linspace(-1.0, 2.0, n)[rs:re], n)
+        y = P.Vec.from_array(comm, np.cos(np.arange(n))[rs:re], n)
+        red = [x.dot(y), x.norm(), x.norm(P.NORM_1), x.norm(P.NORM_INFINITY), *x.norm(P.NORM_1_AND_2), *x.mdot([y, x, y])]
+        x.destroy(); y.destroy()
+        return out, red
+
+    host = run_ranks(size, lambda comm: body(comm, True))
+    dev = run_ranks(size, lambda comm: body(comm, False))
+    ref_g = orc.operator(ai, aj, aa, size).solve(b, "gmres", "jacobi", rtol=1e-9)
+    ref_c = orc.operator(*sym, size).solve(bs, "cg", "jacobi", rtol=1e-9)
+    for res in (host, dev):
+        check_ksp([r[0][0] for r in res], ref_g)
+        check_ksp([r[0][1] for r in res], ref_c)
+        for r in res[1:]:
+            assert r[1] == res[0][1]  # every rank holds the same bits
+    np.testing.assert_allclose(host[0][1], dev[0][1], rtol=1e-13)
+
+
 def test_cg_variants(orc):
     """norm types (cg.c:136-160), -ksp_cg_single_reduction (cg.c:226-243), non-zero initial guess (cg.c:131-132)."""
     from petsc_amd import generators as G, petsc as P

@@ -502,11 +502,17 @@ def test_byproduct_tickets(ctx, orc):
             # MultAdd in place adds its increment's share to the same ticket (no publish: read the device slot)
             t2 = Ticket()
             ctx.check(L.phip_mat_mult_dot(A, dx, dy, dv, 0, C.byref(t2)))
-            ctx.check(L.phip_mat_multadd_dot(A, dx, dy, dv, C.byref(t2)))
+            ctx.check(L.phip_mat_multadd_dot(A, dx, dy, dv, 0, C.byref(t2)))
             dvp = C.c_void_p()
             ctx.check(L.phip_ticket_values(ctx.h, C.byref(t2), C.byref(dvp)))
             assert abs(ctx.to_host(dvp, 1)[0] - 2.0 * (v @ yo)) <= 1e-11 * np.abs(v * yo).sum()
             assert relerr(ctx.to_host(dy, n), 2.0 * yo) <= 1e-12
+            # ... and with publish the accumulated value reaches the ticket's host slot (the multi-rank path: diag block, then off-diag)
+            t3 = Ticket()
+            ctx.check(L.phip_mat_mult_dot(A, dx, dy, dv, 0, C.byref(t3)))
+            ctx.check(L.phip_mat_multadd_dot(A, dx, dy, dv, 1, C.byref(t3)))
+            ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t3), val.ctypes.data_as(C.POINTER(C.c_double))))
+            assert abs(val[0] - 2.0 * (v @ yo)) <= 1e-11 * np.abs(v * yo).sum()
             for p in (dx, dv, dy):
                 ctx.free(p)
             ctx.check(L.phip_mat_destroy(A))
