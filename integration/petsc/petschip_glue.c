@@ -129,13 +129,8 @@ static PetscErrorCode VecHIPByProductFetch(Vec w,PetscBool *ok)
   PetscFunctionBegin;
   *ok = PETSC_FALSE;
   if (!b->havehost) {
-    if (!VHIP(w)->ismpi) { if (phip_ticket_wait(hipctx,&b->ticket,b->host)) { b->live = PETSC_FALSE; PetscFunctionReturn(0); } }
-    else {
-      double *d;
-      if (phip_ticket_values(hipctx,&b->ticket,&d)) { b->live = PETSC_FALSE; PetscFunctionReturn(0); }
-      CHKERRPHIP(phip_comm_allreduce(hipcomm,d,b->ticket.nvals,0));
-      CHKERRPHIP(phip_read_scalars(hipctx,d,b->ticket.nvals,b->host));
-    }
+    if (phip_ticket_wait(hipctx,&b->ticket,b->host)) { b->live = PETSC_FALSE; PetscFunctionReturn(0); }   /* expires identically on every rank */
+    if (VHIP(w)->ismpi) CHKERRPHIP(phip_comm_allreduce_host(hipcomm,b->host,b->ticket.nvals,0));             /* the ranks meet on the host */
     b->havehost = PETSC_TRUE;
   }
   *ok = PETSC_TRUE;
@@ -193,14 +188,11 @@ static PetscErrorCode VecDot_HIP(Vec x,Vec y,PetscScalar *z)                  /*
   if (hit) PetscFunctionReturn(0);
   VEC_R(x,px); VEC_R(y,py);
   if (!VHIP(x)->ismpi) CHKERRPHIP(phip_vec_dot(hipctx,x->map->n,px,py,z));
-  else {
-    const double *ys[1]; double *dr;
+  else {                                                      /* VecDot_MPI pbvec.c:9-19: local dot, then the ranks' values are summed */
+    const double *ys[1];
     ys[0] = py;
-    CHKERRPHIP(phip_malloc(hipctx,8,(void**)&dr));            /* a real glue keeps one scratch slot per process */
-    CHKERRPHIP(phip_vec_reduce_local(hipctx,0,x->map->n,px,1,ys,dr));
-    CHKERRPHIP(phip_comm_allreduce(hipcomm,dr,1,0));
-    CHKERRPHIP(phip_read_scalars(hipctx,dr,1,z));
-    CHKERRPHIP(phip_free(hipctx,dr));
+    CHKERRPHIP(phip_vec_reduce_local_host(hipctx,0,x->map->n,px,1,ys,z));
+    CHKERRPHIP(phip_comm_allreduce_host(hipcomm,z,1,0));       /* shared-memory ring of the node; MPI_Allreduce(MPI_IN_PLACE,z,1,MPIU_SCALAR,MPIU_SUM,comm) serves as well */
   }
   ierr = PetscLogFlops(2.0*x->map->n-1);CHKERRQ(ierr);     /* bvec1.c:27 */
   PetscFunctionReturn(0);
@@ -220,14 +212,11 @@ static PetscErrorCode VecNorm_HIP(Vec x,NormType type,PetscReal *z)           /*
   }
   VEC_R(x,px);
   if (!VHIP(x)->ismpi) CHKERRPHIP(phip_vec_norm(hipctx,x->map->n,px,(int)type,z));
-  else {
-    double *dr,r[2];
-    int     kind = (type == NORM_1) ? 2 : (type == NORM_INFINITY) ? 3 : (type == NORM_1_AND_2) ? 4 : 1;
-    CHKERRPHIP(phip_malloc(hipctx,16,(void**)&dr));
-    CHKERRPHIP(phip_vec_reduce_local(hipctx,kind,x->map->n,px,1,NULL,dr));
-    CHKERRPHIP(phip_comm_allreduce(hipcomm,dr,kind == 4 ? 2 : 1,kind == 3 ? 1 : 0));
-    CHKERRPHIP(phip_read_scalars(hipctx,dr,kind == 4 ? 2 : 1,r));
-    CHKERRPHIP(phip_free(hipctx,dr));
+  else {                                                      /* VecNorm_MPI pvec2.c:49-85 */
+    double r[2];
+    int    kind = (type == NORM_1) ? 2 : (type == NORM_INFINITY) ? 3 : (type == NORM_1_AND_2) ? 4 : 1;
+    CHKERRPHIP(phip_vec_reduce_local_host(hipctx,kind,x->map->n,px,1,NULL,r));
+    CHKERRPHIP(phip_comm_allreduce_host(hipcomm,r,kind == 4 ? 2 : 1,kind == 3 ? 1 : 0));
     if (kind == 1) z[0] = PetscSqrtReal(r[0]); else if (kind == 4) { z[0] = r[0]; z[1] = PetscSqrtReal(r[1]); } else z[0] = r[0];
   }
   PetscFunctionReturn(0);
@@ -242,13 +231,9 @@ static PetscErrorCode VecMDot_HIP(Vec x,PetscInt nv,const Vec y[],PetscScalar *z
   VEC_R(x,px);
   for (k=0; k<nv; k++) { VEC_R(y[k],py[k]); }
   if (!VHIP(x)->ismpi) CHKERRPHIP(phip_vec_mdot(hipctx,x->map->n,px,nv,py,z));
-  else {
-    double *dr;
-    CHKERRPHIP(phip_malloc(hipctx,8*nv,(void**)&dr));
-    CHKERRPHIP(phip_vec_reduce_local(hipctx,0,x->map->n,px,nv,py,dr));
-    CHKERRPHIP(phip_comm_allreduce(hipcomm,dr,nv,0));
-    CHKERRPHIP(phip_read_scalars(hipctx,dr,nv,z));
-    CHKERRPHIP(phip_free(hipctx,dr));
+  else {                                                      /* VecMDot_MPI pvec2.c:10-25: one all-reduce of nv scalars */
+    CHKERRPHIP(phip_vec_reduce_local_host(hipctx,0,x->map->n,px,nv,py,z));
+    CHKERRPHIP(phip_comm_allreduce_host(hipcomm,z,nv,0));
   }
   ierr = PetscLogFlops(PetscMax(nv*(2.0*x->map->n-1),0.0));CHKERRQ(ierr);
   PetscFunctionReturn(0);
@@ -303,7 +288,7 @@ static PetscErrorCode VecPointwiseMult_HIP(Vec w,Vec x,Vec y)                 /*
   if (w != x && w != y && x != y) {                            /* PCApply_Jacobi's shape (jacobi.c:288): fuse the reductions KSPCG asks for next */
     phip_ticket t;
     VEC_R(x,px); VEC_R(y,py); VEC_W(w,pw);
-    CHKERRPHIP(phip_vec_pointwise_mult_reduce(hipctx,w->map->n,pw,px,py,!VHIP(w)->ismpi,&t));
+    CHKERRPHIP(phip_vec_pointwise_mult_reduce(hipctx,w->map->n,pw,px,py,1,&t));
     VEC_DONE(w,pw);
     ierr = VecHIPByProductRecord(w,1,&t,x,y);CHKERRQ(ierr);
   } else {
