@@ -289,23 +289,30 @@ extern "C" int phip_comm_create(phip_ctx ctx, const char *backend, const void *i
     c->backend = BACKEND_RCCL;
     PHIP_CHECK_HIP(hipMalloc((void **)&c->d_stage, sizeof(double) * PHIP_MAX_MVEC));
     if (nranks > 1) {
-      /* the host ring needs every rank on one node: compare host names (PHIP_HOST_RING=0 forces the device path) */
+      /* The host ring needs every rank on one node (compare host names; PHIP_HOST_RING=0 forces the device route) and a shared
+         segment every rank can map.  The ranks agree through two all-gathers; if anything is amiss all of them stay on the device route. */
+      PHIP_REQUIRE(nranks <= 1024, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: %d ranks", nranks);
       char     host[256] = {0};
       gethostname(host, sizeof(host) - 1);
-      uint64_t mine = 1469598103934665603ull;
-      for (size_t i = 0; i < sizeof(host); i++) { mine ^= (unsigned char)host[i]; mine *= 1099511628211ull; }
-      if (getenv("PHIP_HOST_RING") && !atoi(getenv("PHIP_HOST_RING"))) mine ^= (uint64_t)rank + 1; /* pretend the ranks are apart */
-      std::vector<uint64_t> all((size_t)nranks);
-      if ((rc = phip_comm_allgather_host(c, &mine, all.data(), sizeof(uint64_t)))) return rc;
-      bool same = true;
-      for (int p = 0; p < nranks; p++) same = same && all[(size_t)p] == all[0];
-      if (same) {
-        if ((rc = hr_attach_shm(c, id128))) return rc;
+      uint64_t rec[2] = {1469598103934665603ull, 1};
+      for (size_t i = 0; i < sizeof(host); i++) { rec[0] ^= (unsigned char)host[i]; rec[0] *= 1099511628211ull; }
+      if (getenv("PHIP_HOST_RING") && !atoi(getenv("PHIP_HOST_RING"))) rec[0] ^= (uint64_t)rank + 1; /* pretend the ranks are apart */
+      if (rank == 0) rec[1] = hr_attach_shm(c, id128) == 0; /* rank 0 creates the segment before anyone looks for it */
+      std::vector<uint64_t> all((size_t)2 * nranks);
+      if ((rc = phip_comm_allgather_host(c, rec, all.data(), sizeof(rec)))) return rc;
+      bool go = all[1] != 0;
+      for (int p = 0; p < nranks; p++) go = go && all[(size_t)2 * p] == all[0];
+      uint64_t ok = 1;
+      if (go && rank != 0) ok = hr_attach_shm(c, id128) == 0;
+      std::vector<uint64_t> oks((size_t)nranks);
+      if ((rc = phip_comm_allgather_host(c, &ok, oks.data(), sizeof(ok)))) return rc;
+      for (int p = 0; p < nranks; p++) go = go && oks[(size_t)p] != 0;
+      if (go) {
         const unsigned char *peers[1024];
-        PHIP_REQUIRE(nranks <= 1024, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: %d ranks on one node", nranks);
-        if ((rc = hr_round(c, &mine, sizeof(mine), peers))) { if (rank == 0) shm_unlink(c->hr.name); return rc; } /* everyone has mapped the segment: its name can go */
-        if (rank == 0) shm_unlink(c->hr.name);
-      }
+        rc = hr_round(c, &ok, sizeof(ok), peers); /* everyone has mapped the segment: its name can go */
+      } else hr_detach(c);
+      if (rank == 0 && all[1]) shm_unlink(c->hr.name);
+      if (rc) return rc;
     }
   } else if (!strcmp(backend, "shm")) {
     PHIP_REQUIRE(id128, PHIP_ERR_ARG_NULL, "phip_comm_create: shm backend needs a 128-byte key shared by the ranks");
