@@ -1835,19 +1835,44 @@ extern "C" PetscErrorCode MatLoad(Mat A, const char *filename, int64_t *offset)
   ierr = read_f64(f, la.data(), lnz); if (ierr) { fclose(f); return ierr; }
   fclose(f);
   if (offset) *offset = vals0 + 8 * (int64_t)nz;
-  /* insert row by row (MatSetValues_SeqAIJ / _MPIAIJ, aij.c:4163-4171, mpiaij.c:3051): rows in the file need not be sorted */
+  /* preallocate exactly (mpiaij.c:3010-3040 counts the diagonal / off-diagonal entries of every row the same way) */
   std::vector<PetscInt> dn((size_t)m), on((size_t)m);
   const PetscInt cstart = A->crange[(size_t)A->comm->rank], cend = A->crange[(size_t)A->comm->rank + 1];
+  bool sorted = true;
   for (PetscInt r = 0; r < m; r++) {
     PetscInt d = 0;
-    for (PetscInt k = li[(size_t)r]; k < li[(size_t)r + 1]; k++) d += (lj[(size_t)k] >= cstart && lj[(size_t)k] < cend);
+    for (PetscInt k = li[(size_t)r]; k < li[(size_t)r + 1]; k++) {
+      if (lj[(size_t)k] < 0 || lj[(size_t)k] >= N) SETERRQ(PETSC_ERR_FILE_UNEXPECTED, "Column %d out of range in row %d of the file", lj[(size_t)k], rstart + r);
+      d += (lj[(size_t)k] >= cstart && lj[(size_t)k] < cend);
+      if (k > li[(size_t)r] && lj[(size_t)k] <= lj[(size_t)k - 1]) sorted = false;
+    }
     dn[(size_t)r] = A->mpi ? d : li[(size_t)r + 1] - li[(size_t)r]; on[(size_t)r] = li[(size_t)r + 1] - li[(size_t)r] - d;
   }
   if (A->mpi) { ierr = MatMPIAIJSetPreallocation(A, 0, dn.data(), 0, on.data()); CHKERRQ(ierr); }
   else { ierr = MatSeqAIJSetPreallocation(A, 0, dn.data()); CHKERRQ(ierr); }
-  for (PetscInt r = 0; r < m; r++) {
-    const PetscInt grow = rstart + r;
-    ierr = MatSetValues(A, 1, &grow, li[(size_t)r + 1] - li[(size_t)r], lj.data() + li[(size_t)r], la.data() + li[(size_t)r], INSERT_VALUES); CHKERRQ(ierr);
+  if (sorted) {
+    /* rows as MatView writes them (sorted, unique columns): every rank lays its slab straight into the diagonal / off-diagonal blocks --
+       the result of the reference's row-by-row MatSetValues (aij.c:4163-4171, mpiaij.c:3051) without its per-entry searches
+        */
+    for (PetscInt r = 0; r < m; r++) {
+      size_t pa = (size_t)A->A.start[(size_t)r], pb = A->mpi ? (size_t)A->B.start[(size_t)r] : 0;
+      for (PetscInt k = li[(size_t)r]; k < li[(size_t)r + 1]; k++) {
+        const PetscInt c = lj[(size_t)k];
+        if (!A->mpi) { A->A.j[pa] = c; A->A.a[pa++] = la[(size_t)k]; }
+        else if (c >= cstart && c < cend) { A->A.j[pa] = c - cstart; A->A.a[pa++] = la[(size_t)k]; }
+        else { A->B.j[pb] = c; A->B.a[pb++] = la[(size_t)k]; }
+      }
+      A->A.len[(size_t)r] = dn[(size_t)r];
+      if (A->mpi) A->B.len[(size_t)r] = on[(size_t)r];
+    }
+    A->A.nonzerostate++; A->A.values_dirty = true;
+    if (A->mpi) { A->B.nonzerostate++; A->B.values_dirty = true; }
+  } else {
+    /* unsorted rows (the format allows them): sorted insertion, row by row */
+    for (PetscInt r = 0; r < m; r++) {
+      const PetscInt grow = rstart + r;
+      ierr = MatSetValues(A, 1, &grow, li[(size_t)r + 1] - li[(size_t)r], lj.data() + li[(size_t)r], la.data() + li[(size_t)r], INSERT_VALUES); CHKERRQ(ierr);
+    }
   }
   ierr = MatAssemblyBegin(A, MAT_FINAL_ASSEMBLY); CHKERRQ(ierr);
   return MatAssemblyEnd(A, MAT_FINAL_ASSEMBLY);

@@ -86,6 +86,27 @@ def test_matload_matview_binary(comm, golden_dir, tmp_path, name):
     A.destroy()
 
 
+def test_matload_unsorted_rows(comm, golden_dir, tmp_path):
+    """The file format does not promise sorted rows: MatLoad lays sorted slabs straight into the blocks and falls back to sorted
+    insertion (MatSetValues row by row, aij.c:4163-4171) otherwise -- same matrix either way."""
+    from petsc_amd import petsc as P
+    g = load(golden_dir, "small")
+    ai, aj, aa = g["i"], g["j"].copy(), g["a"].copy()
+    rng = np.random.default_rng(2)
+    for r in range(len(ai) - 1):
+        p = rng.permutation(ai[r + 1] - ai[r]) + ai[r]
+        aj[ai[r]:ai[r + 1]], aa[ai[r]:ai[r + 1]] = aj[p], aa[p]
+    path = str(tmp_path / "shuffled.dat")
+    with open(path, "wb") as f:
+        f.write(np.array([1211216, int(g["M"]), int(g["N"]), len(aj)], ">i4").tobytes())
+        f.write(np.diff(ai).astype(">i4").tobytes()); f.write(aj.astype(">i4").tobytes()); f.write(aa.astype(">f8").tobytes())
+    A = P.Mat(comm)
+    A.load(path)
+    blk = A.block(0)
+    np.testing.assert_array_equal(blk["i"], g["i"]); np.testing.assert_array_equal(blk["j"], g["j"]); np.testing.assert_array_equal(blk["a"], g["a"])
+    A.destroy()
+
+
 def test_error_behaviour(comm):
     from petsc_amd import petsc as P
     with pytest.raises(P.PetscError) as e:
