@@ -6,7 +6,8 @@
 #include <string.h>
 #include "../../include/petschip.h"
 
-#define PHIP_RED_BLOCKS 1024 /* grid of every reduction kernel: fixed => deterministic summation tree */
+#define PHIP_RED_BLOCKS 4096 /* capacity of the partial-result rows: the largest grid a kernel with a fused reduction may have */
+#define PHIP_RED_GRID 1024   /* grid cap of the vector reduction kernels (2048 measured slower); the summation tree depends on the grid only */
 #define PHIP_THREADS 256
 
 #define PHIP_RING 64

@@ -76,18 +76,20 @@ __device__ __forceinline__ void reduce_tail(double (&acc)[NV], double *lds /* >=
   }
   __syncthreads();
   if (!s_last) return;
-  /* last workgroup: wave w sums partial rows w, w+4, ...: 16 values per lane in index order, then the 64-lane tree (a fixed order
-     for a given grid, whichever workgroup arrives last); all of a row's loads are in flight at once */
+  /* last workgroup: wave w sums partial rows w, w+4, ...: lane l adds the values l, l+64, l+128, ... in that order (16 loads in flight
+     at a time), then the 64-lane tree -- a fixed order for a given grid, whichever workgroup arrives last */
   const int w = t >> 6, lane = t & 63;
   if (MODE == 1) {
     if (w == 0) {
       double m = 0.0, f = 0.0;
+      for (int j0 = 0; j0 * 64 < nb; j0 += 16) {
 #pragma unroll
-      for (int j = 0; j < PHIP_RED_BLOCKS / 64; j++) {
-        const int i = lane + 64 * j;
-        if (i < nb) {
-          m = fmax(m, __hip_atomic_load(&c.partial[(size_t)c.kofs * PHIP_RED_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          f = fmax(f, __hip_atomic_load(&c.partial[(size_t)(c.kofs + 1) * PHIP_RED_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        for (int j = 0; j < 16; j++) {
+          const int i = lane + 64 * (j0 + j);
+          if (i < nb) {
+            m = fmax(m, __hip_atomic_load(&c.partial[(size_t)c.kofs * PHIP_RED_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            f = fmax(f, __hip_atomic_load(&c.partial[(size_t)(c.kofs + 1) * PHIP_RED_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          }
         }
       }
       m = wave_max(m); f = wave_max(f);
@@ -96,15 +98,17 @@ __device__ __forceinline__ void reduce_tail(double (&acc)[NV], double *lds /* >=
   } else {
     for (int k = w; k < NV; k += PHIP_THREADS / 64) {
       const double *row = c.partial + (size_t)(c.kofs + k) * PHIP_RED_BLOCKS;
-      double        v[PHIP_RED_BLOCKS / 64];
+      double        s = 0.0;
+      for (int j0 = 0; j0 * 64 < nb; j0 += 16) {
+        double v[16];
 #pragma unroll
-      for (int j = 0; j < PHIP_RED_BLOCKS / 64; j++) {
-        const int i = lane + 64 * j;
-        v[j] = (i < nb) ? __hip_atomic_load(&row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        for (int j = 0; j < 16; j++) {
+          const int i = lane + 64 * (j0 + j);
+          v[j] = (i < nb) ? __hip_atomic_load(&row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) s += v[j];
       }
-      double s = 0.0;
-#pragma unroll
-      for (int j = 0; j < PHIP_RED_BLOCKS / 64; j++) s += v[j];
       s = wave_sum(s);
       if (lane == 0) c.d_out[c.kofs + k] = c.accumulate ? c.d_out[c.kofs + k] + s : s;
     }

@@ -152,7 +152,7 @@ __device__ __forceinline__ void spmv_reduce_rows(const double *prod, const int32
 }
 
 /* DOT: also accumulate sum_i dotv[i] * (A x)_i (the increment, for MultAdd) and leave it where ctl says; the grid then strides over
-   the row blocks with at most PHIP_RED_BLOCKS workgroups.  Without DOT the grid is one workgroup per row block. */
+   the row blocks with a capped number of workgroups (launch_spmv_t).  Without DOT the grid is one workgroup per row block. */
 template <bool DOT, bool NT>
 __global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(int32_t nblocks, const int32_t *__restrict__ blkrow, const uint8_t *__restrict__ blktpr,
                                                                      const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx,
@@ -622,7 +622,12 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
 {
   hipStream_t st = A->ctx->stream;
   if (A->sell_on) {
-    const unsigned grid = DOT ? (unsigned)(A->sell_nslices < PHIP_RED_BLOCKS ? A->sell_nslices : PHIP_RED_BLOCKS) : (unsigned)A->sell_nslices;
+    /* with the fused dot the grid is capped (the tail sums one partial per workgroup).  Measured on 7-point 128^3, CG it/s: cap 1024
+       11.32 k, 2048 11.08 k, 4096 11.10 k -- the cost of the fused dot is its tail (partials -> last workgroup -> pinned host slot),
+       not occupancy.  PHIP_SPMV_DOT_GRID overrides (<= PHIP_RED_BLOCKS) */
+    static const int dot_grid_env = getenv("PHIP_SPMV_DOT_GRID") ? atoi(getenv("PHIP_SPMV_DOT_GRID")) : 0;
+    const int      dot_cap = (dot_grid_env > 0 && dot_grid_env <= PHIP_RED_BLOCKS) ? dot_grid_env : 1024;
+    const unsigned grid = DOT ? (unsigned)(A->sell_nslices < dot_cap ? A->sell_nslices : dot_cap) : (unsigned)A->sell_nslices;
     const bool     nt = 9 * A->sell_padded > PHIP_NT_MATRIX_BYTES;
     /* LDS staging of x is correct but measured SLOWER than gathering through L1/L2 (7-point 128^3: 26.9 -> 31.8 us; 27-point 160^3:
        206 -> 220 us): the gathers are not what bounds this kernel.  Off unless PHIP_SELL_STAGE=1. */
@@ -638,7 +643,9 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     else SELL_LAUNCH(false, false);
 #undef SELL_LAUNCH
   } else {
-    const unsigned grid = DOT ? (unsigned)(A->nblocks < PHIP_RED_BLOCKS ? (A->nblocks > 0 ? A->nblocks : 1) : PHIP_RED_BLOCKS) : (unsigned)A->nblocks;
+    static const int dot_grid_env = getenv("PHIP_SPMV_DOT_GRID") ? atoi(getenv("PHIP_SPMV_DOT_GRID")) : 0;
+    const int      dot_cap = (dot_grid_env > 0 && dot_grid_env <= PHIP_RED_BLOCKS) ? dot_grid_env : 1024;
+    const unsigned grid = DOT ? (unsigned)(A->nblocks < dot_cap ? (A->nblocks > 0 ? A->nblocks : 1) : dot_cap) : (unsigned)A->nblocks;
     /* out-of-cache irregular matrices: non-temporal matrix stream (R-MAT scale 22: 546 -> 505 us); PHIP_CSR_NT=0/1 overrides */
     static const int csr_nt_env = getenv("PHIP_CSR_NT") ? atoi(getenv("PHIP_CSR_NT")) : -1;
     const bool       csr_nt = csr_nt_env >= 0 ? csr_nt_env != 0 : (12 * A->nnz > PHIP_NT_MATRIX_BYTES && !A->use_cprow);

@@ -3,7 +3,7 @@
 // Every kernel is HBM-bound: grid-stride over 16-byte (double2) accesses, tail handled by scalar code.
 // Algorithmic bytes: dot 16n, norm 8n, axpy/aypx/pointwise 24n, waxpy 24n, scale 16n, copy 16n, set 8n,
 // mdot(nv) 8n(nv+1), maxpy(nv) 8n(nv+2).
-// Reductions: fixed grid of PHIP_RED_BLOCKS workgroups; wavefront (64-lane) shuffle reduction -> LDS across the 4 waves ->
+// Reductions: fixed grid of at most PHIP_RED_GRID workgroups; wavefront (64-lane) shuffle reduction -> LDS across the 4 waves ->
 // one partial per workgroup, stored write-through (sc1); the workgroup whose arrival ticket is last sums the partials in a
 // fixed order (deterministic for a given n, whichever workgroup that is), writes the result to device memory and, for the calls
 // that return a host scalar, into a pinned slot followed by a sequence word the host spins on: one launch per reduction,
@@ -312,7 +312,7 @@ extern "C" int phip_vec_pointwise_mult_reduce(phip_ctx c, int32_t n, double *d_w
   RedCtl ctl;
   int    rc = phip_ticket_open(c, 3, publish, t, &ctl);
   if (rc) return rc;
-  hipLaunchKernelGGL(pmult_reduce_kernel, dim3(phip_grid_for((int64_t)n / 2 + 1, 4, PHIP_RED_BLOCKS)), dim3(PHIP_THREADS), 0, c->stream, n, d_w, d_x, d_y, ctl);
+  hipLaunchKernelGGL(pmult_reduce_kernel, dim3(phip_grid_for((int64_t)n / 2 + 1, 4, PHIP_RED_GRID)), dim3(PHIP_THREADS), 0, c->stream, n, d_w, d_x, d_y, ctl);
   PHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -360,7 +360,7 @@ static void launch_mdot(phip_ctx c, int32_t n, const double *d_x, const MVPack &
   hipLaunchKernelGGL((mdot_kernel<NV>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, P, ctl);
 }
 
-static int reduce_grid(int32_t n) { return phip_grid_for((int64_t)n / 2 + 1, 4, PHIP_RED_BLOCKS); }
+static int reduce_grid(int32_t n) { return phip_grid_for((int64_t)n / 2 + 1, 4, PHIP_RED_GRID); }
 
 /* One reduction: results into d_out[0..nres); when publish != 0 also into the pinned slot, with sequence number *seq_out */
 static int reduce_launch(phip_ctx c, int kind, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *d_out, int publish,
