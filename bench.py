@@ -224,26 +224,44 @@ def main():
 
 
 def cpu_baseline(ai, aj, aa, m, iter_bytes, spmv_bytes, seconds):
-    """The oracle (oracle/petsc_oracle.c, -O3 -march=native) on one host core: CG+Jacobi iterations on the same matrix."""
+    """The oracle (oracle/petsc_oracle.c, gcc -O3 -march=native -fopenmp) on the host: KSPCG+PCJACOBI iterations of the same system,
+    (i) as MATMPIAIJ would run it on P cores -- P row blocks, one thread each (P = this job's CPU share) -- and (ii) on one core
+    (MATSEQAIJ).  SURVEY.md 8d."""
     from oracle.oracle import Oracle
     orc = Oracle(fast=True)
-    op = orc.operator(ai, aj, aa, 1)
-    bvec = op.mult(np.ones(m))
-    t = time.perf_counter()
-    op.solve(bvec, "cg", "jacobi", rtol=1e-300, abstol=1e-300, divtol=1e300, max_it=3)
-    per = (time.perf_counter() - t) / 4.0
-    its = int(max(5, min(2000, seconds / max(per, 1e-6))))
-    t = time.perf_counter()
-    r = op.solve(bvec, "cg", "jacobi", rtol=1e-300, abstol=1e-300, divtol=1e300, max_it=its)
-    dt = time.perf_counter() - t
-    t = time.perf_counter()
-    nmult = 5
-    for _ in range(nmult):
-        op.mult(bvec)
-    dts = (time.perf_counter() - t) / nmult
-    return {"value": round(iter_bytes * r["its"] / dt / 1e9, 2), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": "%d KSPCG+PCJACOBI iterations of the same matrix and right-hand side by the oracle's C restatement of MatMult_SeqAIJ/Vec*_Seq (one thread, gcc -O3 -march=native), %.1f s" % (r["its"], dt),
-            "cg_iters_per_s": round(r["its"] / dt, 2), "spmv_GBps": round(spmv_bytes / dts / 1e9, 2)}
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    P = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), avail, 16))
+
+    def leg(size, threads, budget):
+        op = orc.operator(ai, aj, aa, size, threads)
+        bvec = op.mult(np.ones(m))
+        t = time.perf_counter()
+        op.solve(bvec, "cg", "jacobi", rtol=1e-300, abstol=1e-300, divtol=1e300, max_it=3)
+        per = (time.perf_counter() - t) / 4.0
+        its = int(max(5, min(5000, budget / max(per, 1e-6))))
+        t = time.perf_counter()
+        r = op.solve(bvec, "cg", "jacobi", rtol=1e-300, abstol=1e-300, divtol=1e300, max_it=its)
+        dt = time.perf_counter() - t
+        t = time.perf_counter()
+        nmult = 5
+        for _ in range(nmult):
+            op.mult(bvec)
+        dts = (time.perf_counter() - t) / nmult
+        return r["its"], dt, dts
+
+    its1, dt1, dts1 = leg(1, 1, seconds / 2)
+    out = {"value": round(iter_bytes * its1 / dt1 / 1e9, 2), "unit": "GB/s", "cores": 1, "kind": "port",
+           "sample": "%d KSPCG+PCJACOBI iterations of the same matrix and right-hand side by the oracle's C restatement of MatMult_SeqAIJ/Vec*_Seq (one thread, gcc -O3 -march=native), %.1f s" % (its1, dt1),
+           "cg_iters_per_s": round(its1 / dt1, 2), "spmv_GBps": round(spmv_bytes / dts1 / 1e9, 2)}
+    if P > 1:
+        itsP, dtP, dtsP = leg(P, P, seconds / 2)
+        out = {"value": round(iter_bytes * itsP / dtP / 1e9, 2), "unit": "GB/s", "cores": P, "kind": "port",
+               "sample": "%d KSPCG+PCJACOBI iterations of the same system by the oracle's C restatement of MatMult_MPIAIJ/Vec*_MPI: %d row blocks (MPIAIJ's partition), one OpenMP thread each (gcc -O3 -march=native -fopenmp), %.1f s; one_core = the same on a single thread" % (itsP, P, dtP),
+               "cg_iters_per_s": round(itsP / dtP, 2), "spmv_GBps": round(spmv_bytes / dtsP / 1e9, 2), "one_core": out}
+    return out
 
 
 if __name__ == "__main__":

@@ -27,7 +27,9 @@ def build(fast=False, outdir=None):
     src = os.path.join(_HERE, "petsc_oracle.c")
     if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src) and not (fast and outdir == _HERE):
         return out
-    flags = ["-O3", "-march=native"] if fast else ["-O2", "-ffp-contract=off"]
+    # the pinned build has no OpenMP: its rank loops run one after the other.  The fast build (CPU baseline of bench.py) may spread
+    # the emulated ranks over threads (OracleOperator(threads=...)).
+    flags = ["-O3", "-march=native", "-fopenmp"] if fast else ["-O2", "-ffp-contract=off"]
     subprocess.check_call(["gcc", "-std=gnu99", *flags, "-fPIC", "-shared", "-fvisibility=hidden", "-o", out, src, "-lm"])
     return out
 
@@ -308,19 +310,22 @@ class Oracle:
         return d
 
     # ---- operator + KSP --------------------------------------------------------------------
-    def operator(self, gi, gj, ga, size=1):
-        return OracleOperator(self, gi, gj, ga, size)
+    def operator(self, gi, gj, ga, size=1, threads=1):
+        return OracleOperator(self, gi, gj, ga, size, threads)
 
 
 class OracleOperator:
     """Row-block distributed (MPIAIJ-shaped) operator emulated in one process."""
 
-    def __init__(self, orc, gi, gj, ga, size=1):
+    def __init__(self, orc, gi, gj, ga, size=1, threads=1):
+        """threads > 1 (fast build only): the emulated ranks run on that many OpenMP threads -- same results, the CPU baseline of
+        'size ranks of MPIAIJ on size cores'."""
         self.orc = orc
         self.gi, self.gj, self.ga = _i32(gi), _i32(gj), _f64(ga)
         self.N = len(self.gi) - 1
         self.size = size
-        self.h = C.c_void_p(orc.lib.orc_operator_create(C.c_int32(self.N), C.c_int32(size), _ip(self.gi), _ip(self.gj), _dp(self.ga)))
+        orc.lib.orc_operator_create_threaded.restype = C.c_void_p
+        self.h = C.c_void_p(orc.lib.orc_operator_create_threaded(C.c_int32(self.N), C.c_int32(size), _ip(self.gi), _ip(self.gj), _dp(self.ga), C.c_int(threads)))
 
     def __del__(self):
         try:

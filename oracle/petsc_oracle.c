@@ -689,9 +689,28 @@ typedef struct {
   /* compressed-row data of B_r (MatAssemblyEnd_SeqAIJ on B, aij.c:1020) */
   int *Bcp_use; OInt *Bcp_n; OInt **Bcp_i, **Bcp_r;
   double *lvec;             /* scratch, max ec */
+  double **lvecs;           /* one ghost buffer per rank (lvec of mmaij.c:104) */
+  int threads;              /* > 1: the ranks' work runs on that many OpenMP threads, one rank per thread at a time -- the CPU baseline
+                               "P ranks of MPIAIJ on P cores" (SURVEY.md 8d); needs a build with -fopenmp, otherwise sequential.
+                               Results do not depend on it: ranks are independent and reductions are summed in rank order. */
 } OrcOperator;
 
+/* loop over the emulated ranks, in parallel when the operator asks for it (the pragma is ignored without -fopenmp) */
+#define ORC_PRAGMA(x) _Pragma(#x)
+#define ORC_FOR_RANKS(op, r) ORC_PRAGMA(omp parallel for schedule(static, 1) num_threads((op)->threads > 1 ? (op)->threads : 1)) \
+  for (r = 0; r < (op)->size; r++)
+
+static OrcOperator *orc_operator_create_t(OInt N, OInt size, const OInt *gi, const OInt *gj, const double *ga, int threads);
 ORC_EXPORT OrcOperator *orc_operator_create(OInt N, OInt size, const OInt *gi, const OInt *gj, const double *ga)
+{
+  return orc_operator_create_t(N, size, gi, gj, ga, 1);
+}
+/* the same operator with its ranks spread over OpenMP threads (CPU baseline only) */
+ORC_EXPORT OrcOperator *orc_operator_create_threaded(OInt N, OInt size, const OInt *gi, const OInt *gj, const double *ga, int threads)
+{
+  return orc_operator_create_t(N, size, gi, gj, ga, threads);
+}
+static OrcOperator *orc_operator_create_t(OInt N, OInt size, const OInt *gi, const OInt *gj, const double *ga, int threads)
 {
   OrcOperator *op = (OrcOperator *)calloc(1, sizeof(*op));
   OInt r, maxec = 0;
@@ -703,7 +722,9 @@ ORC_EXPORT OrcOperator *orc_operator_create(OInt N, OInt size, const OInt *gi, c
   op->ec = (OInt *)calloc(size, sizeof(OInt)); op->garray = (OInt **)calloc(size, sizeof(OInt *));
   op->Bcp_use = (int *)calloc(size, sizeof(int)); op->Bcp_n = (OInt *)calloc(size, sizeof(OInt));
   op->Bcp_i = (OInt **)calloc(size, sizeof(OInt *)); op->Bcp_r = (OInt **)calloc(size, sizeof(OInt *));
-  for (r = 0; r < size; r++) {
+  op->lvecs = (double **)calloc(size, sizeof(double *));
+  op->threads = threads;
+  ORC_FOR_RANKS(op, r) { /* each rank's blocks are allocated and filled by the thread that will use them (first touch) */
     OInt rs = op->range[r], re = op->range[r + 1], m = re - rs, nzA, nzB, k, nzrows = 0;
     OInt *li = (OInt *)malloc(((size_t)m + 1) * sizeof(OInt));
     for (k = 0; k <= m; k++) li[k] = gi[rs + k] - gi[rs];
@@ -712,12 +733,13 @@ ORC_EXPORT OrcOperator *orc_operator_create(OInt N, OInt size, const OInt *gi, c
     op->Bi[r] = (OInt *)malloc(((size_t)m + 1) * sizeof(OInt)); op->Bj[r] = (OInt *)malloc(((size_t)nzB + 1) * sizeof(OInt)); op->Ba[r] = (double *)malloc(((size_t)nzB + 1) * sizeof(double));
     op->garray[r] = (OInt *)malloc(((size_t)nzB + 1) * sizeof(OInt));
     op->ec[r] = orc_mpiaij_split(m, N, li, gj + gi[rs], ga + gi[rs], rs, re, op->Ai[r], op->Aj[r], op->Aa[r], op->Bi[r], op->Bj[r], op->Ba[r], op->garray[r]);
-    if (op->ec[r] > maxec) maxec = op->ec[r];
+    op->lvecs[r] = (double *)calloc((size_t)op->ec[r] + 1, sizeof(double));
     for (k = 0; k < m; k++) nzrows += (op->Bi[r][k + 1] - op->Bi[r][k]) > 0;
     op->Bcp_i[r] = (OInt *)malloc(((size_t)m + 1) * sizeof(OInt)); op->Bcp_r[r] = (OInt *)malloc(((size_t)m + 1) * sizeof(OInt));
     op->Bcp_use[r] = orc_check_compressed_row(m, op->Bi[r], nzrows, 0.6, &op->Bcp_n[r], op->Bcp_i[r], op->Bcp_r[r]);
     free(li);
   }
+  for (r = 0; r < size; r++) if (op->ec[r] > maxec) maxec = op->ec[r];
   op->lvec = (double *)malloc(((size_t)maxec + 1) * sizeof(double));
   return op;
 }
@@ -728,21 +750,23 @@ ORC_EXPORT void orc_operator_destroy(OrcOperator *op)
   if (!op) return;
   for (r = 0; r < op->size; r++) {
     free(op->Ai[r]); free(op->Aj[r]); free(op->Aa[r]); free(op->Bi[r]); free(op->Bj[r]); free(op->Ba[r]);
-    free(op->garray[r]); free(op->Bcp_i[r]); free(op->Bcp_r[r]);
+    free(op->garray[r]); free(op->Bcp_i[r]); free(op->Bcp_r[r]); free(op->lvecs[r]);
   }
+  free(op->lvecs);
   free(op->Ai); free(op->Aj); free(op->Aa); free(op->Bi); free(op->Bj); free(op->Ba); free(op->ec); free(op->garray);
   free(op->Bcp_use); free(op->Bcp_n); free(op->Bcp_i); free(op->Bcp_r); free(op->range); free(op->lvec); free(op);
 }
 
 ORC_EXPORT void orc_operator_mult(OrcOperator *op, const double *x, double *y)
 {
-  OInt r, k;
-  for (r = 0; r < op->size; r++) {
-    OInt rs = op->range[r], m = op->range[r + 1] - rs;
-    for (k = 0; k < op->ec[r]; k++) op->lvec[k] = x[op->garray[r][k]];            /* VecScatterBegin/End */
+  OInt r;
+  ORC_FOR_RANKS(op, r) {
+    OInt rs = op->range[r], m = op->range[r + 1] - rs, k;
+    double *lvec = op->lvecs[r];
+    for (k = 0; k < op->ec[r]; k++) lvec[k] = x[op->garray[r][k]];                /* VecScatterBegin/End */
     orc_matmult_seqaij(m, op->Ai[r], op->Aj[r], op->Aa[r], 0, 0, NULL, NULL, x + rs, y + rs);  /* A->mult */
     orc_matmultadd_seqaij(m, op->Bi[r], op->Bj[r], op->Ba[r], op->Bcp_use[r], op->Bcp_n[r], op->Bcp_i[r], op->Bcp_r[r],
-                          op->lvec, y + rs, y + rs);                              /* B->multadd(lvec,y,y) */
+                          lvec, y + rs, y + rs);                                  /* B->multadd(lvec,y,y) */
   }
 }
 
@@ -779,17 +803,23 @@ ORC_EXPORT void orc_operator_getdiagonal(OrcOperator *op, double *d) /* mpiaij.c
 static double orc_op_dot(const OrcOperator *op, const double *x, const double *y)
 {
   OInt r; double s = 0.0;
-  for (r = 0; r < op->size; r++) s += orc_vecdot(op->range[r + 1] - op->range[r], x + op->range[r], y + op->range[r]);
+  double *part = (double *)malloc((size_t)op->size * sizeof(double));
+  ORC_FOR_RANKS(op, r) part[r] = orc_vecdot(op->range[r + 1] - op->range[r], x + op->range[r], y + op->range[r]);
+  for (r = 0; r < op->size; r++) s += part[r];  /* MPI_Allreduce(SUM): rank order here */
+  free(part);
   return s;
 }
 static double orc_op_norm2(const OrcOperator *op, const double *x)
 {
   OInt r; double s = 0.0;
-  for (r = 0; r < op->size; r++) {
+  double *part = (double *)malloc((size_t)op->size * sizeof(double));
+  ORC_FOR_RANKS(op, r) {
     OInt n = op->range[r + 1] - op->range[r], i; const double *xx = x + op->range[r]; double w = 0.0;
     for (i = 0; i < n; i++) w += xx[i] * xx[i];
-    s += w;                                  /* pvec2.c:59-65: local dot, Allreduce SUM, sqrt */
+    part[r] = w;
   }
+  for (r = 0; r < op->size; r++) s += part[r]; /* pvec2.c:59-65: local dot, Allreduce SUM, sqrt */
+  free(part);
   return sqrt(s);
 }
 static void orc_op_mdot(const OrcOperator *op, const double *x, OInt nv, double *const *y, double *z)
@@ -847,10 +877,23 @@ static int orc_converged_default(OrcKSP *k, OInt n, double rnorm, const OrcOpera
 
 static void orc_hist(OrcKSP *k, double r) { if (k->hist && k->nhist < k->hist_cap) k->hist[k->nhist] = r; k->nhist++; }
 
+/* elementwise kernels rank by rank (every rank owns a slice of the vectors, as the MPI Vec type does): the same values as one
+   call over the whole vector, on op->threads threads when asked */
+static void orc_op_pointwisemult(const OrcOperator *op, double *w, const double *x, const double *y)
+{ OInt r; ORC_FOR_RANKS(op, r) orc_vecpointwisemult(op->range[r + 1] - op->range[r], w + op->range[r], x + op->range[r], y + op->range[r]); }
+static void orc_op_copy(const OrcOperator *op, const double *x, double *y)
+{ OInt r; ORC_FOR_RANKS(op, r) orc_veccopy(op->range[r + 1] - op->range[r], x + op->range[r], y + op->range[r]); }
+static void orc_op_set(const OrcOperator *op, double *x, double a)
+{ OInt r; ORC_FOR_RANKS(op, r) orc_vecset(op->range[r + 1] - op->range[r], x + op->range[r], a); }
+static void orc_op_axpy(const OrcOperator *op, double *y, double a, const double *x)
+{ OInt r; ORC_FOR_RANKS(op, r) orc_vecaxpy(op->range[r + 1] - op->range[r], y + op->range[r], a, x + op->range[r]); }
+static void orc_op_aypx(const OrcOperator *op, double *y, double a, const double *x)
+{ OInt r; ORC_FOR_RANKS(op, r) orc_vecaypx(op->range[r + 1] - op->range[r], y + op->range[r], a, x + op->range[r]); }
+
 static void orc_pcapply(const OrcOperator *op, const double *d, const double *x, double *y)
 {
-  if (d) orc_vecpointwisemult(op->N, y, x, d); /* PCApply_Jacobi jacobi.c:288 */
-  else orc_veccopy(op->N, x, y);               /* PCNONE */
+  if (d) orc_op_pointwisemult(op, y, x, d);    /* PCApply_Jacobi jacobi.c:288 */
+  else orc_op_copy(op, x, y);                  /* PCNONE */
 }
 
 /* KSPSolve_CG, src/ksp/ksp/impls/cg/cg.c:93-279 (no single-reduction, no eigenvalue estimate);
@@ -862,8 +905,8 @@ ORC_EXPORT int orc_ksp_cg(OrcOperator *op, OrcKSP *ksp, const double *d, const d
   double *R = (double *)malloc((size_t)N * sizeof(double)), *Z = (double *)malloc((size_t)N * sizeof(double));
   double *P = (double *)malloc((size_t)N * sizeof(double)), *W = Z, *T = (double *)malloc((size_t)N * sizeof(double));
   ksp->its = 0; ksp->reason = 0; ksp->nhist = 0;
-  if (ksp->guess_nonzero) { orc_operator_mult(op, X, R); orc_vecaypx(N, R, -1.0, B); } /* cg.c:131-132 */
-  else { orc_vecset(N, X, 0.0); orc_veccopy(N, B, R); }                                /* :134 */
+  if (ksp->guess_nonzero) { orc_operator_mult(op, X, R); orc_op_aypx(op, R, -1.0, B); } /* cg.c:131-132 */
+  else { orc_op_set(op, X, 0.0); orc_op_copy(op, B, R); }                                /* :134 */
   switch (ksp->normtype) {
   case 1: orc_pcapply(op, d, R, Z); dp = orc_op_norm2(op, Z); break;                   /* :139-140 */
   case 2: dp = orc_op_norm2(op, R); break;                                             /* :143 */
@@ -880,8 +923,8 @@ ORC_EXPORT int orc_ksp_cg(OrcOperator *op, OrcKSP *ksp, const double *d, const d
     ksp->its = i + 1;
     if (beta == 0.0) { ksp->reason = ORC_CONVERGED_ATOL; break; }                      /* :182-185 */
     else if ((i > 0) && (beta * betaold < 0.0)) { ksp->reason = ORC_DIVERGED_INDEFINITE_PC; break; }
-    if (!i) { orc_veccopy(N, Z, P); b = 0.0; }                                         /* :194 */
-    else { b = beta / betaold; orc_vecaypx(N, P, b, Z); }                              /* :197,202 */
+    if (!i) { orc_op_copy(op, Z, P); b = 0.0; }                                         /* :194 */
+    else { b = beta / betaold; orc_op_aypx(op, P, b, Z); }                              /* :197,202 */
     dpiold = dpi;
     orc_operator_mult(op, P, W);                                                       /* :206 */
     dpi = orc_op_dot(op, P, W);                                                        /* :207 */
@@ -889,8 +932,8 @@ ORC_EXPORT int orc_ksp_cg(OrcOperator *op, OrcKSP *ksp, const double *d, const d
     if (isnan(beta) || isinf(beta)) { ksp->reason = ORC_DIVERGED_NANORINF; break; }    /* KSPCheckDot :213 */
     if ((dpi == 0.0) || ((i > 0) && (dpi * dpiold <= 0.0))) { ksp->reason = ORC_DIVERGED_INDEFINITE_MAT; break; }
     a = beta / dpi;                                                                    /* :220 */
-    orc_vecaxpy(N, X, a, P);                                                           /* :222 */
-    orc_vecaxpy(N, R, -a, W);                                                          /* :223 */
+    orc_op_axpy(op, X, a, P);                                                           /* :222 */
+    orc_op_axpy(op, R, -a, W);                                                          /* :223 */
     if (ksp->normtype == 1) { orc_pcapply(op, d, R, Z); dp = orc_op_norm2(op, Z); }    /* :225,229 */
     else if (ksp->normtype == 2) dp = orc_op_norm2(op, R);                             /* :231 */
     else if (ksp->normtype == 3) { orc_pcapply(op, d, R, Z); beta = orc_op_dot(op, Z, R); dp = sqrt(fabs(beta)); }

@@ -249,3 +249,19 @@ def test_cg_jacobi_poisson(orc, golden_dir):
     assert np.linalg.norm(op.mult(res["x"]) - b) <= 1e-10 * np.linalg.norm(b)
     res2 = orc.operator(g["i"], g["j"], g["a"], 3).solve(b, "cg", "jacobi", rtol=1e-12)
     assert abs(res2["its"] - res["its"]) <= 1
+
+
+def test_threaded_ranks_same_bits(tmp_path):
+    """The CPU baseline of bench.py spreads the emulated MPIAIJ ranks over OpenMP threads (fast build, -fopenmp): ranks are independent
+    and reductions are summed in rank order, so the results are bit-identical to the one-thread emulation."""
+    from oracle import oracle
+    from petsc_amd import generators as G
+    o = oracle.Oracle(path=oracle.build(fast=True, outdir=str(tmp_path)))
+    ai, aj, aa = G.laplace3d_7pt(20, dirichlet_rows=False)
+    n = len(ai) - 1
+    b = o.operator(ai, aj, aa, 1).mult(np.ones(n))
+    seq = o.operator(ai, aj, aa, 4, 1).solve(b, "cg", "jacobi", rtol=1e-8)
+    par = o.operator(ai, aj, aa, 4, 4).solve(b, "cg", "jacobi", rtol=1e-8)
+    assert seq["its"] == par["its"] and seq["rnorm"] == par["rnorm"]
+    np.testing.assert_array_equal(seq["x"], par["x"])
+    np.testing.assert_array_equal(seq["history"], par["history"])
