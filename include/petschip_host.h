@@ -40,6 +40,7 @@ typedef struct _p_Vec *Vec;
 typedef struct _p_Mat *Mat;
 typedef struct _p_PC  *PC;
 typedef struct _p_KSP *KSP;
+typedef struct _p_PetscRandom *PetscRandom;
 
 typedef enum { NOT_SET_VALUES = 0, INSERT_VALUES = 1, ADD_VALUES = 2 } InsertMode;             /* include/petscsys.h */
 typedef enum { MAT_FLUSH_ASSEMBLY = 1, MAT_FINAL_ASSEMBLY = 0 } MatAssemblyType;               /* include/petscmat.h */
@@ -123,6 +124,16 @@ PetscErrorCode VecMTDot(Vec x, PetscInt nv, const Vec y[], PetscScalar val[]);  
 PetscErrorCode VecDotNorm2(Vec s, Vec t, PetscScalar *dp, PetscReal *nm);           /* vinv.c:1369: dp = s.t, nm = t.t */
 PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val);
 PetscErrorCode VecNormalize(Vec x, PetscReal *val);
+PetscErrorCode VecPlaceArray(Vec v, const PetscScalar array[]);   /* rvector.c:1955; ops->placearray (veccusp.cu:1974) */
+PetscErrorCode VecResetArray(Vec v);                              /* rvector.c:2008 */
+/* PetscRandom of type rand48 (src/sys/classes/random/impls/rand48/rand48.c) and VecSetRandom (vector.c:1205; rctx may be NULL) */
+PetscErrorCode PetscRandomCreate(PetscComm comm, PetscRandom *r);
+PetscErrorCode PetscRandomSetSeed(PetscRandom r, unsigned long seed);
+PetscErrorCode PetscRandomSeed(PetscRandom r);
+PetscErrorCode PetscRandomSetInterval(PetscRandom r, PetscScalar low, PetscScalar high);
+PetscErrorCode PetscRandomGetValue(PetscRandom r, PetscScalar *val);
+PetscErrorCode PetscRandomDestroy(PetscRandom *r);
+PetscErrorCode VecSetRandom(Vec x, PetscRandom rctx);
 
 /* ---- Mat (include/petscmat.h; wrappers src/mat/interface/matrix.c) ---- */
 PetscErrorCode MatRegister(const char *sname, PetscErrorCode (*ctor)(Mat));

@@ -235,6 +235,8 @@ struct _p_Vec {
   bool        setup;
   double     *d;          /* device array */
   std::vector<double> h;  /* host mirror handed out by VecGetArray */
+  double     *placed = NULL;        /* VecPlaceArray: the caller's array stands in for the host mirror until VecResetArray ... */
+  std::vector<double> unplaced;     /* ... which brings these values back (the vector's own array, untouched meanwhile: bvec2.c:687-735) */
   int         host_out;   /* 0 none, 1 read access outstanding, 2 write access outstanding */
   uint64_t    state;      /* PetscObjectState: bumped on every write (rvector.c:1865 et al.) */
   std::vector<PetscInt> stash_i; std::vector<double> stash_v; std::vector<int> stash_mode;
@@ -577,9 +579,10 @@ extern "C" PetscErrorCode VecGetArrayRead(Vec v, const PetscScalar **a)
 {
   VecCheckReady(v, "VecGetArrayRead");
   v->h.resize((size_t)v->n + 1);
-  CHKPHIP(phip_memcpy_d2h(VCTX(v), v->h.data(), v->d, sizeof(double) * (size_t)v->n));
+  double *host = v->placed ? v->placed : v->h.data();
+  CHKPHIP(phip_memcpy_d2h(VCTX(v), host, v->d, sizeof(double) * (size_t)v->n));
   v->host_out = 1;
-  *a = v->h.data();
+  *a = host;
   return 0;
 }
 extern "C" PetscErrorCode VecRestoreArrayRead(Vec v, const PetscScalar **a)
@@ -594,19 +597,103 @@ extern "C" PetscErrorCode VecGetArray(Vec v, PetscScalar **a)
   const PetscScalar *r;
   PetscErrorCode     ierr = VecGetArrayRead(v, &r); CHKERRQ(ierr);
   v->host_out = 2;
-  *a = v->h.data();
+  *a = v->placed ? v->placed : v->h.data();
   return 0;
 }
 extern "C" PetscErrorCode VecRestoreArray(Vec v, PetscScalar **a)
 {
   if (!v) SETERRQ(PETSC_ERR_ARG_NULL, "VecRestoreArray: null vector");
   if (v->host_out != 2) SETERRQ(PETSC_ERR_ORDER, "VecRestoreArray: no VecGetArray() outstanding");
-  CHKPHIP(phip_memcpy_h2d(VCTX(v), v->d, v->h.data(), sizeof(double) * (size_t)v->n));
+  CHKPHIP(phip_memcpy_h2d(VCTX(v), v->d, v->placed ? v->placed : v->h.data(), sizeof(double) * (size_t)v->n));
   v->host_out = 0;
   v->state++; /* rvector.c:1865 */
   if (a) *a = NULL;
   return 0;
 }
+/* VecPlaceArray / VecResetArray (rvector.c:1955-2030; ops->placearray/resetarray, veccusp.cu:1974-1976): the vector takes the values of
+   the caller's array and hands that array out from VecGetArray until the reset, which restores the vector's own values */
+extern "C" PetscErrorCode VecPlaceArray(Vec v, const PetscScalar array[])
+{
+  VecCheckReady(v, "VecPlaceArray");
+  if (!array && v->n) SETERRQ(PETSC_ERR_ARG_NULL, "VecPlaceArray: null array");
+  if (v->placed) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "VecPlaceArray() was already called on this vector, without a call to VecResetArray()"); /* bvec2.c:693 */
+  if (v->host_out) SETERRQ(PETSC_ERR_ORDER, "VecPlaceArray: VecGetArray() is outstanding");
+  v->unplaced.resize((size_t)v->n + 1);
+  CHKPHIP(phip_memcpy_d2h(VCTX(v), v->unplaced.data(), v->d, sizeof(double) * (size_t)v->n));
+  v->placed = const_cast<PetscScalar *>(array);
+  CHKPHIP(phip_memcpy_h2d(VCTX(v), v->d, array, sizeof(double) * (size_t)v->n));
+  v->state++;
+  return 0;
+}
+extern "C" PetscErrorCode VecResetArray(Vec v)
+{
+  VecCheckReady(v, "VecResetArray");
+  if (v->host_out) SETERRQ(PETSC_ERR_ORDER, "VecResetArray: VecGetArray() is outstanding");
+  if (!v->placed) return 0;
+  /* what the device holds now belongs to the placed array (the reference computes in it in place) */
+  CHKPHIP(phip_memcpy_d2h(VCTX(v), v->placed, v->d, sizeof(double) * (size_t)v->n));
+  CHKPHIP(phip_memcpy_h2d(VCTX(v), v->d, v->unplaced.data(), sizeof(double) * (size_t)v->n));
+  v->placed = NULL; v->unplaced.clear();
+  v->state++;
+  return 0;
+}
+
+/* PetscRandom, type rand48 (src/sys/classes/random/impls/rand48/rand48.c:6-42, interface randomc.c:335-350): seed 0x12345678 + 76543*rank,
+   srand48(seed) at type set-up, value = width*drand48() + low when an interval is set.  erand48 on the object's own state gives
+   drand48's sequence without its process-wide state (ranks may be threads here). */
+struct _p_PetscRandom {
+  PetscComm      comm;
+  unsigned long  seed;
+  unsigned short x[3];
+  double         low, width;
+  bool           iset;
+};
+extern "C" PetscErrorCode PetscRandomSeed(PetscRandom r)
+{
+  if (!r) SETERRQ(PETSC_ERR_ARG_NULL, "PetscRandomSeed: null object");
+  r->x[0] = 0x330E; r->x[1] = (unsigned short)(r->seed & 0xFFFF); r->x[2] = (unsigned short)((r->seed >> 16) & 0xFFFF); /* srand48(3) */
+  return 0;
+}
+extern "C" PetscErrorCode PetscRandomCreate(PetscComm comm, PetscRandom *r)
+{
+  if (!comm || !r) SETERRQ(PETSC_ERR_ARG_NULL, "PetscRandomCreate: null argument");
+  PetscRandom q = new _p_PetscRandom();
+  q->comm = comm; q->low = 0.0; q->width = 1.0; q->iset = false;
+  q->seed = 0x12345678ul + 76543ul * (unsigned long)comm->rank; /* randomc.c:347 */
+  *r = q;
+  return PetscRandomSeed(q); /* PetscRandomSetType, randreg.c:51 */
+}
+extern "C" PetscErrorCode PetscRandomSetSeed(PetscRandom r, unsigned long seed) { if (!r) SETERRQ(PETSC_ERR_ARG_NULL, "PetscRandomSetSeed: null object"); r->seed = seed; return 0; }
+extern "C" PetscErrorCode PetscRandomSetInterval(PetscRandom r, PetscScalar low, PetscScalar high)
+{
+  if (!r) SETERRQ(PETSC_ERR_ARG_NULL, "PetscRandomSetInterval: null object");
+  if (low >= high) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "only low < high: Instead %g %g", low, high); /* randomc.c PetscRandomSetInterval */
+  r->low = low; r->width = high - low; r->iset = true;
+  return 0;
+}
+extern "C" PetscErrorCode PetscRandomGetValue(PetscRandom r, PetscScalar *val)
+{
+  if (!r || !val) SETERRQ(PETSC_ERR_ARG_NULL, "PetscRandomGetValue: null argument");
+  const double u = erand48(r->x);
+  *val = r->iset ? r->width * u + r->low : u; /* rand48.c:40-41 */
+  return 0;
+}
+extern "C" PetscErrorCode PetscRandomDestroy(PetscRandom *r) { if (r && *r) { delete *r; *r = NULL; } return 0; }
+/* VecSetRandom vector.c:1205-1231 -> VecSetRandom_Seq bvec2.c:  xx[i] = PetscRandomGetValue, i ascending over the local part; the values are
+   made on the host and sent to the device once (as VecSetRandom_SeqCUSP's host fallback would) */
+extern "C" PetscErrorCode VecSetRandom(Vec x, PetscRandom rctx)
+{
+  VecCheckReady(x, "VecSetRandom");
+  PetscRandom    own = NULL;
+  PetscErrorCode ierr;
+  if (!rctx) { ierr = PetscRandomCreate(x->comm, &own); CHKERRQ(ierr); rctx = own; }
+  PetscScalar *a;
+  ierr = VecGetArray(x, &a); CHKERRQ(ierr);
+  for (PetscInt i = 0; i < x->n; i++) { ierr = PetscRandomGetValue(rctx, &a[i]); CHKERRQ(ierr); }
+  ierr = VecRestoreArray(x, &a); CHKERRQ(ierr);
+  return PetscRandomDestroy(&own);
+}
+
 extern "C" PetscErrorCode VecHipGetArrayRead(Vec v, const PetscScalar **d_a) { VecCheckReady(v, "VecHipGetArrayRead"); *d_a = v->d; return 0; }
 extern "C" PetscErrorCode VecHipGetArrayWrite(Vec v, PetscScalar **d_a) { VecCheckReady(v, "VecHipGetArrayWrite"); *d_a = v->d; v->state++; return 0; }
 

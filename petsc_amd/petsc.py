@@ -29,8 +29,9 @@ PETSC_DEFAULT = -2
 _SCALAR = {"PetscInt": C.c_int32, "int32_t": C.c_int32, "int": C.c_int, "PetscBool": C.c_int, "PetscScalar": C.c_double,
            "PetscReal": C.c_double, "double": C.c_double, "int64_t": C.c_int64, "PetscErrorCode": C.c_int,
            "InsertMode": C.c_int, "MatAssemblyType": C.c_int, "NormType": C.c_int, "KSPNormType": C.c_int,
-           "KSPGMRESCGSRefinementType": C.c_int, "PCJacobiType": C.c_int, "KSPConvergedReason": C.c_int}
-_HANDLES = {"PetscComm", "Vec", "Mat", "PC", "KSP", "phip_ctx"}
+           "KSPGMRESCGSRefinementType": C.c_int, "PCJacobiType": C.c_int, "KSPConvergedReason": C.c_int,
+           "unsigned": C.c_ulong}  # the only unsigned parameter is PetscRandomSetSeed's `unsigned long`
+_HANDLES = {"PetscComm", "Vec", "Mat", "PC", "KSP", "phip_ctx", "PetscRandom"}
 
 
 def _ctype(decl):
@@ -317,6 +318,28 @@ class Vec:
         z = np.zeros(len(ys))
         chk(lib().VecMDot(self.h, len(ys), arr, _p(z)))
         return z
+
+    def set_random(self, seed=None, interval=None):
+        """VecSetRandom with a rand48 PetscRandom (default seed 0x12345678 + 76543*rank, randomc.c:347)."""
+        r = C.c_void_p()
+        chk(lib().PetscRandomCreate(self.comm.h, C.byref(r)))
+        if seed is not None:
+            chk(lib().PetscRandomSetSeed(r, seed))
+            chk(lib().PetscRandomSeed(r))
+        if interval is not None:
+            chk(lib().PetscRandomSetInterval(r, float(interval[0]), float(interval[1])))
+        chk(lib().VecSetRandom(self.h, r))
+        chk(lib().PetscRandomDestroy(C.byref(r)))
+
+    def place_array(self, a):
+        """VecPlaceArray: `a` (float64, contiguous, local length) must stay alive until reset_array()."""
+        assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and len(a) == self.local_size
+        self._placed = a
+        chk(lib().VecPlaceArray(self.h, a.ctypes.data_as(C.c_void_p)))
+
+    def reset_array(self):
+        chk(lib().VecResetArray(self.h))
+        self._placed = None
 
     def mtdot(self, ys):
         arr = (C.c_void_p * max(len(ys), 1))(*[y.h for y in ys])

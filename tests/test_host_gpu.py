@@ -129,6 +129,49 @@ def test_vec_closed_forms_ex1():
         assert all(run_ranks(size, body))
 
 
+def test_setrandom_placearray():
+    """VecSetRandom with the default rand48 PetscRandom (rand48.c:6-42; seed 0x12345678 + 76543*rank, randomc.c:347) reproduces glibc's
+    srand48/drand48 sequence; VecPlaceArray / VecResetArray (rvector.c:1955-2030) swap the values in and out."""
+    import ctypes as C
+    from petsc_amd import petsc as P
+    libc = C.CDLL(None)
+    libc.drand48.restype = C.c_double
+
+    def rand48(seed, n):
+        libc.srand48(C.c_long(seed))
+        return np.array([libc.drand48() for _ in range(n)])
+
+    N = 1000
+
+    def body(comm):
+        x = P.Vec(comm, P.PETSC_DECIDE, N, "hip")
+        x.set_random()
+        a = x.array().copy()
+        x.set_random(seed=42, interval=(-2.0, 3.0))
+        b = x.array().copy()
+        mine = np.arange(x.local_size, dtype=np.float64) + 100.0 * comm.rank
+        x.set(7.0)
+        x.place_array(mine)
+        assert np.array_equal(x.array(), mine)
+        x.scale(2.0)                       # computes on the placed values ...
+        nrm = x.norm(P.NORM_INFINITY)
+        x.reset_array()
+        assert np.array_equal(mine, 2.0 * (np.arange(len(mine)) + 100.0 * comm.rank))   # ... which the caller's array holds afterwards
+        assert np.array_equal(x.array(), np.full(len(mine), 7.0))                       # the vector's own values are back
+        with pytest.raises(P.PetscError):
+            x.place_array(mine); x.place_array(mine)
+        x.reset_array()
+        x.destroy()
+        return a, b, nrm
+
+    for size in (1, 3):
+        res = run_ranks(size, body)
+        for r, (a, b, nrm) in enumerate(res):
+            np.testing.assert_array_equal(a, rand48(0x12345678 + 76543 * r, len(a)))
+            np.testing.assert_array_equal(b, 5.0 * rand48(42, len(b)) + -2.0)
+        assert res[0][2] == max(2.0 * (len(a) - 1 + 100.0 * r) for r, (a, _, _) in enumerate(res))
+
+
 @pytest.mark.parametrize("name", ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64"])
 @pytest.mark.parametrize("size", [1, 2, 3, 4])
 def test_matmult_golden(orc, golden_dir, name, size):
