@@ -311,6 +311,50 @@ def test_scale_diagonalscale_shift(golden_dir, size):
             assert np.abs(g_ - ref).max() <= 1e-12 * (np.abs(ref).max() + 1e-300)
 
 
+def test_ranks_without_rows(orc):
+    """More ranks than rows (PetscSplitOwnership gives some ranks nothing, psplit.c:88), a diagonal matrix (no ghost entries anywhere)
+    and a matrix whose ranks all talk to all others: products, reductions and a solve still agree with the oracle."""
+    from petsc_amd import petsc as P
+    rng = np.random.default_rng(31)
+    cases = []
+    n = 3
+    cases.append((np.array([0, 2, 5, 7], np.int32), np.array([0, 1, 0, 1, 2, 1, 2], np.int32), np.array([4.0, -1, -1, 4, -1, -1, 4])))
+    n2 = 37
+    cases.append((np.arange(n2 + 1, dtype=np.int32), np.arange(n2, dtype=np.int32), rng.uniform(1.0, 2.0, n2)))
+    import scipy.sparse as sp
+    D = sp.random(29, 29, density=0.6, random_state=5, format="csr") + sp.identity(29) * 30.0
+    D = (D + D.T).tocsr(); D.sort_indices()
+    cases.append((D.indptr.astype(np.int32), D.indices.astype(np.int32), D.data.copy()))
+    for ai, aj, aa in cases:
+        N = len(ai) - 1
+        xg = rng.standard_normal(N)
+        bg = orc.operator(ai, aj, aa, 1).mult(np.ones(N))
+
+        def body(comm):
+            rs, re = local_slice(comm, N)
+            A = P.Mat.from_global_csr(comm, ai, aj, aa)
+            x = P.Vec.from_array(comm, xg[rs:re], N)
+            y = x.duplicate()
+            A.mult(x, y)
+            out = [y.array(), x.dot(y), x.norm(), x.norm(P.NORM_INFINITY)]
+            A.mult_transpose(x, y)
+            out.append(y.array())
+            out.append(ksp_case(comm, ai, aj, aa, bg, "cg", rtol=1e-10))
+            for o in (x, y, A):
+                o.destroy()
+            return out
+
+        for size in (2, 4, 5):
+            res = run_ranks(size, body)
+            op = orc.operator(ai, aj, aa, size)
+            yref = op.mult(xg)
+            assert np.abs(gather([r[0] for r in res]) - yref).max() <= 1e-12 * np.abs(yref).max()
+            assert abs(res[0][1] - xg @ yref) <= 1e-12 * np.abs(xg * yref).sum()
+            assert abs(res[0][2] - np.linalg.norm(xg)) <= 1e-13 * np.linalg.norm(xg) and res[0][3] == np.abs(xg).max()
+            assert np.abs(gather([r[4] for r in res]) - op.mult_transpose(xg)).max() <= 1e-12 * np.abs(yref).max()
+            check_ksp([r[5] for r in res], op.solve(bg, "cg", "jacobi", rtol=1e-10))
+
+
 def ksp_case(comm, ai, aj, aa, b_global, ksp_type, pc="jacobi", x0=None, **opts):
     from petsc_amd import petsc as P
     N = len(ai) - 1
