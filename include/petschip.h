@@ -177,6 +177,10 @@ int phip_mat_mult_dot(phip_mat A, const double *d_x, double *d_y, const double *
 /* y += A x in place (phip_mat_multadd with z == y, mpiaij.c:996); adds sum_i v_i (y_new_i - y_old_i) to the value of the live ticket t;
  * publish != 0 also delivers the accumulated value to the ticket's host slot (phip_ticket_wait), for a ticket opened without publish */
 int phip_mat_multadd_dot(phip_mat A, const double *d_x, double *d_y, const double *d_v, int publish, const phip_ticket *t);
+/* Split reductions (VecDotBegin/VecNormBegin ... VecDotEnd, src/vec/vec/utils/comb.c:  begin the reduction, queue other work, collect the
+ * result later): the local kernel is launched without waiting and delivers its raw sums (kind and layout as phip_vec_reduce_local, at most
+ * 7 values) to the ticket; phip_ticket_wait collects them, phip_comm_allreduce_host combines the ranks. */
+int phip_vec_reduce_begin(phip_ctx ctx, int kind, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, phip_ticket *t);
 int phip_ticket_values(phip_ctx ctx, const phip_ticket *t, double **d_vals);
 int phip_ticket_wait(phip_ctx ctx, const phip_ticket *t, double *h_vals);
 

@@ -62,6 +62,7 @@ typedef enum { /* include/petscksp.h:385-405 */
 #define MATAIJHIP "aijhip"
 #define KSPCG "cg"
 #define KSPGMRES "gmres"
+#define KSPPIPECG "pipecg" /* src/ksp/ksp/impls/cg/pipecg/pipecg.c: one split reduction per iteration, overlapped with PCApply + MatMult */
 #define PCNONE "none"
 #define PCJACOBI "jacobi"
 
@@ -124,6 +125,14 @@ PetscErrorCode VecMTDot(Vec x, PetscInt nv, const Vec y[], PetscScalar val[]);  
 PetscErrorCode VecDotNorm2(Vec s, Vec t, PetscScalar *dp, PetscReal *nm);           /* vinv.c:1369: dp = s.t, nm = t.t */
 PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val);
 PetscErrorCode VecNormalize(Vec x, PetscReal *val);
+/* split reductions, src/vec/vec/utils/comb.c: Begin launches the local kernel without waiting; the first End combines everything queued */
+PetscErrorCode VecDotBegin(Vec x, Vec y, PetscScalar *result);
+PetscErrorCode VecDotEnd(Vec x, Vec y, PetscScalar *result);
+PetscErrorCode VecTDotBegin(Vec x, Vec y, PetscScalar *result);
+PetscErrorCode VecTDotEnd(Vec x, Vec y, PetscScalar *result);
+PetscErrorCode VecNormBegin(Vec x, NormType ntype, PetscReal *result);
+PetscErrorCode VecNormEnd(Vec x, NormType ntype, PetscReal *result);
+PetscErrorCode PetscCommSplitReductionBegin(PetscComm comm);
 PetscErrorCode VecPlaceArray(Vec v, const PetscScalar array[]);   /* rvector.c:1955; ops->placearray (veccusp.cu:1974) */
 PetscErrorCode VecResetArray(Vec v);                              /* rvector.c:2008 */
 /* PetscRandom of type rand48 (src/sys/classes/random/impls/rand48/rand48.c) and VecSetRandom (vector.c:1205; rctx may be NULL) */

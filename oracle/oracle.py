@@ -362,7 +362,7 @@ class OracleOperator:
                       C.c_int(normtype), C.c_int32(restart), C.c_int(cgs_refine))
         hist = np.zeros(max_it + 2)
         L.orc_ksp_set_history(k, _dp(hist), C.c_int32(len(hist)))
-        fn = L.orc_ksp_cg if ksp_type == "cg" else L.orc_ksp_gmres
+        fn = {"cg": L.orc_ksp_cg, "pipecg": L.orc_ksp_pipecg, "gmres": L.orc_ksp_gmres}[ksp_type]
         fn(self.h, k, _dp(d) if d is not None else None, _dp(b), _dp(x))
         its, reason, rnorm, nh = C.c_int32(0), C.c_int(0), C.c_double(0), C.c_int32(0)
         L.orc_ksp_get(k, C.byref(its), C.byref(reason), C.byref(rnorm), C.byref(nh))

@@ -951,6 +951,64 @@ done:
   return 0;
 }
 
+/* KSPSolve_PIPECG, src/ksp/ksp/impls/cg/pipecg/pipecg.c:31-169.  The split reductions (VecNormBegin/VecDotBegin ... End, comb.c)
+   deliver the same values as the blocking calls: local sums, then one SUM over the ranks.                       */
+ORC_EXPORT int orc_ksp_pipecg(OrcOperator *op, OrcKSP *ksp, const double *d, const double *B, double *X)
+{
+  OInt   N = op->N, i, q;
+  double alpha = 0.0, beta = 0.0, gamma = 0.0, gammaold = 0.0, delta = 0.0, dp = 0.0;
+  double *w[9], *M, *Z, *P, *Nn, *W, *Q, *U, *R, *S;
+  for (q = 0; q < 9; q++) w[q] = (double *)calloc((size_t)N + 1, sizeof(double));
+  M = w[0]; Z = w[1]; P = w[2]; Nn = w[3]; W = w[4]; Q = w[5]; U = w[6]; R = w[7]; S = w[8];
+  ksp->its = 0; ksp->reason = 0; ksp->nhist = 0;
+  if (ksp->guess_nonzero) { orc_operator_mult(op, X, R); orc_op_aypx(op, R, -1.0, B); }   /* :62-63 */
+  else { orc_op_set(op, X, 0.0); orc_op_copy(op, B, R); }                                 /* itfunc.c:580, :65 */
+  orc_pcapply(op, d, R, U);                                                                /* :68 */
+  switch (ksp->normtype) {
+  case 1: orc_operator_mult(op, U, W); dp = orc_op_norm2(op, U); break;                    /* :72-75 */
+  case 2: orc_operator_mult(op, U, W); dp = orc_op_norm2(op, R); break;                    /* :78-81 */
+  case 3: orc_operator_mult(op, U, W); gamma = orc_op_dot(op, R, U);                       /* :84-87 */
+          if (isnan(gamma) || isinf(gamma)) { ksp->reason = ORC_DIVERGED_NANORINF; goto done; }
+          dp = sqrt(fabs(gamma)); break;
+  default: orc_operator_mult(op, U, W); dp = 0.0;
+  }
+  orc_hist(ksp, dp); ksp->rnorm = dp;
+  ksp->reason = orc_converged_default(ksp, 0, dp, op, B, d, M);                            /* :101 */
+  if (ksp->reason) goto done;
+  i = 0;
+  do {
+    orc_pcapply(op, d, W, M);                                                              /* :117 */
+    orc_operator_mult(op, M, Nn);                                                          /* :118 */
+    if (i > 0 && ksp->normtype == 2) dp = orc_op_norm2(op, R);                             /* :106-110 / :120-124 */
+    else if (i > 0 && ksp->normtype == 1) dp = orc_op_norm2(op, U);
+    if (!(i == 0 && ksp->normtype == 3)) gamma = orc_op_dot(op, R, U);                     /* :111-113 / :125-127 */
+    delta = orc_op_dot(op, W, U);                                                          /* :114 / :128 */
+    if (i > 0) {
+      if (ksp->normtype == 3) dp = sqrt(fabs(gamma));
+      else if (ksp->normtype != 1 && ksp->normtype != 2) dp = 0.0;
+      ksp->rnorm = dp; orc_hist(ksp, dp);
+      ksp->reason = orc_converged_default(ksp, i, dp, op, B, d, M);                      /* :137 (the work vector is only written at i == 0) */
+      if (ksp->reason) break;
+    }
+    if (i == 0) {
+      alpha = gamma / delta;
+      orc_op_copy(op, Nn, Z); orc_op_copy(op, M, Q); orc_op_copy(op, U, P); orc_op_copy(op, W, S);   /* :143-146 */
+    } else {
+      beta = gamma / gammaold;
+      alpha = gamma / (delta - beta / alpha * gamma);                                      /* :149 */
+      orc_op_aypx(op, Z, beta, Nn); orc_op_aypx(op, Q, beta, M); orc_op_aypx(op, P, beta, U); orc_op_aypx(op, S, beta, W); /* :150-153 */
+    }
+    orc_op_axpy(op, X, alpha, P); orc_op_axpy(op, U, -alpha, Q); orc_op_axpy(op, W, -alpha, Z); orc_op_axpy(op, R, -alpha, S); /* :155-158 */
+    gammaold = gamma;
+    i++;
+    ksp->its = i;
+  } while (i < ksp->max_it);
+  if (i >= ksp->max_it && !ksp->reason) ksp->reason = ORC_DIVERGED_ITS;
+done:
+  for (q = 0; q < 9; q++) free(w[q]);
+  return 0;
+}
+
 /* KSPSolve_GMRES / KSPGMRESCycle / KSPGMRESBuildSoln / KSPGMRESUpdateHessenberg,
    src/ksp/ksp/impls/gmres/gmres.c:118-246,316-418, classical Gram-Schmidt borthog2.c:36-111,
    KSPInitialResidual itres.c:39-70, left preconditioning KSP_PCApplyBAorAB = MatMult then PCApply

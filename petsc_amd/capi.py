@@ -70,6 +70,7 @@ SIGNATURES = [
     ("phip_ticket_wait", C.c_int, [_vp, _vp, _pD]),
     ("phip_jacobi_setup", C.c_int, [_vp, C.c_int32, _vp, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     ("phip_vec_reduce_local", C.c_int, [_vp, C.c_int, C.c_int32, _vp, C.c_int32, C.POINTER(_vp), _vp]),
+    ("phip_vec_reduce_begin", C.c_int, [_vp, C.c_int, C.c_int32, _vp, C.c_int32, C.POINTER(_vp), _vp]),
     ("phip_vec_reduce_local_host", C.c_int, [_vp, C.c_int, C.c_int32, _vp, C.c_int32, C.POINTER(_vp), _pD]),
     ("phip_read_scalars", C.c_int, [_vp, _vp, C.c_int32, _pD]),
     ("phip_comm_create_callbacks", C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.POINTER(_vp)]),

@@ -63,6 +63,7 @@ struct _p_PetscComm {
   bool      bp_on[3];
   int       bp_streak[3];
   _p_PetscComm *root; /* the world communicator that owns the switches (self shares them) */
+  struct SplitReduction *split; /* VecDotBegin/VecNormBegin ... queue (comb.c), made on first use */
 };
 #define BP(c) ((c)->root)
 
@@ -136,10 +137,12 @@ static bool ctx_has_device(phip_ctx ctx)
   return dev >= 0;
 }
 
+static void split_free(PetscComm c);
 extern "C" PetscErrorCode PetscHipFinalize(PetscComm *world)
 {
   if (!world || !*world) return 0;
   PetscComm w = *world;
+  split_free(w->self); split_free(w);
   phip_comm_destroy(w->self->comm);
   phip_comm_destroy(w->comm);
   phip_free(w->ctx, w->d_red);
@@ -864,6 +867,106 @@ extern "C" PetscErrorCode VecDotNorm2(Vec s, Vec t, PetscScalar *dp, PetscReal *
   *dp = z[0]; *nm = z[1];
   return 0;
 }
+/* ---- split reductions: VecDotBegin/End, VecTDotBegin/End, VecNormBegin/End, PetscCommSplitReductionBegin (src/vec/vec/utils/comb.c) ----
+   The reference queues the local results and combines all of them in one MPI_Allreduce at the first End (or, non-blocking, at
+   PetscCommSplitReductionBegin), so that the callers in between -- KSPPIPECG's PCApply and MatMult -- hide the reduction's latency.
+   Here every Begin launches its local kernel at once, without waiting; the kernels that the caller queues afterwards run behind it, and
+   by the first End the results usually sit in pinned host memory already: one wait, one host all-reduce of all queued values. */
+struct SplitOp { Vec x, y; int kind; NormType nt; phip_ticket t; int nres; double res[2]; };
+struct SplitReduction { std::vector<SplitOp> ops; size_t ended = 0; bool applied = false; };
+static void split_free(PetscComm c) { delete c->split; c->split = NULL; }
+static SplitReduction *split_of(PetscComm c) { if (!c->split) c->split = new SplitReduction(); return c->split; }
+static PetscErrorCode split_begin(Vec x, Vec y, int kind, NormType nt)
+{
+  SplitReduction *sr = split_of(x->comm);
+  if (sr->applied) { /* comb.c:  a Begin after the Ends of the previous round starts a new round */
+    if (sr->ended != sr->ops.size()) SETERRQ(PETSC_ERR_ORDER, "Called before all VecxxxEnd() called");
+    sr->ops.clear(); sr->ended = 0; sr->applied = false;
+  }
+  SplitOp op;
+  op.x = x; op.y = y; op.kind = kind; op.nt = nt; op.nres = (kind == 4) ? 2 : 1;
+  const double *p[1] = {y ? y->d : NULL};
+  CHKPHIP(phip_vec_reduce_begin(VCTX(x), kind, x->n, x->d, 1, p, &op.t));
+  sr->ops.push_back(op);
+  return 0;
+}
+static PetscErrorCode split_apply(PetscComm c) /* PetscSplitReductionApply, comb.c: one reduction for everything queued */
+{
+  SplitReduction *sr = split_of(c);
+  if (sr->applied) return 0;
+  std::vector<double> sum, mx;
+  for (SplitOp &op : sr->ops) {
+    CHKPHIP(phip_ticket_wait(c->ctx, &op.t, op.res));
+    for (int k = 0; k < op.nres; k++) (op.kind == 3 ? mx : sum).push_back(op.res[k]);
+  }
+  if (c->size > 1) {
+    for (size_t o = 0; o < sum.size(); o += PHIP_MAX_MVEC) CHKPHIP(phip_comm_allreduce_host(c->comm, sum.data() + o, (int32_t)std::min<size_t>(PHIP_MAX_MVEC, sum.size() - o), 0));
+    for (size_t o = 0; o < mx.size(); o += PHIP_MAX_MVEC) CHKPHIP(phip_comm_allreduce_host(c->comm, mx.data() + o, (int32_t)std::min<size_t>(PHIP_MAX_MVEC, mx.size() - o), 1));
+  }
+  size_t is = 0, im = 0;
+  for (SplitOp &op : sr->ops)
+    for (int k = 0; k < op.nres; k++) op.res[k] = (op.kind == 3) ? mx[im++] : sum[is++];
+  sr->applied = true;
+  return 0;
+}
+static PetscErrorCode split_end(Vec x, Vec y, int kind, SplitOp **out)
+{
+  SplitReduction *sr = split_of(x->comm);
+  PetscErrorCode  ierr = split_apply(x->comm); CHKERRQ(ierr);
+  if (sr->ended >= sr->ops.size()) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Called VecxxxEnd() more times then VecxxxBegin()");
+  SplitOp *op = &sr->ops[sr->ended];
+  if (op->x != x || op->y != y || (op->kind == 0) != (kind == 0)) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Called VecxxxEnd() in a different order or with a different vector than VecxxxBegin()");
+  sr->ended++;
+  *out = op;
+  return 0;
+}
+extern "C" PetscErrorCode VecDotBegin(Vec x, Vec y, PetscScalar *result)
+{
+  (void)result;
+  VecCheckReady(x, "VecDotBegin"); VecCheckReady(y, "VecDotBegin"); VecCheckSame(x, y, "VecDotBegin");
+  return split_begin(x, y, 0, NORM_2);
+}
+extern "C" PetscErrorCode VecDotEnd(Vec x, Vec y, PetscScalar *result)
+{
+  VecCheckReady(x, "VecDotEnd");
+  if (!result) SETERRQ(PETSC_ERR_ARG_NULL, "VecDotEnd: null result");
+  SplitOp       *op;
+  PetscErrorCode ierr = split_end(x, y, 0, &op); CHKERRQ(ierr);
+  *result = op->res[0];
+  return 0;
+}
+extern "C" PetscErrorCode VecTDotBegin(Vec x, Vec y, PetscScalar *result) { return VecDotBegin(x, y, result); }
+extern "C" PetscErrorCode VecTDotEnd(Vec x, Vec y, PetscScalar *result) { return VecDotEnd(x, y, result); }
+extern "C" PetscErrorCode VecNormBegin(Vec x, NormType ntype, PetscReal *result)
+{
+  (void)result;
+  VecCheckReady(x, "VecNormBegin");
+  int kind;
+  switch (ntype) {
+  case NORM_2: case NORM_FROBENIUS: kind = 1; break;
+  case NORM_1: kind = 2; break;
+  case NORM_INFINITY: kind = 3; break;
+  case NORM_1_AND_2: kind = 4; break;
+  default: SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "VecNormBegin: unknown NormType %d", (int)ntype);
+  }
+  return split_begin(x, NULL, kind, ntype);
+}
+extern "C" PetscErrorCode VecNormEnd(Vec x, NormType ntype, PetscReal *result)
+{
+  VecCheckReady(x, "VecNormEnd");
+  if (!result) SETERRQ(PETSC_ERR_ARG_NULL, "VecNormEnd: null result");
+  SplitOp       *op;
+  PetscErrorCode ierr = split_end(x, NULL, 1, &op); CHKERRQ(ierr);
+  if (op->nt != ntype) SETERRQ(PETSC_ERR_ARG_WRONGSTATE, "Called VecNormEnd() with a different norm type than VecNormBegin()");
+  if (op->kind == 1) result[0] = sqrt(op->res[0]);
+  else if (op->kind == 4) { result[0] = op->res[0]; result[1] = sqrt(op->res[1]); }
+  else result[0] = op->res[0];
+  return 0;
+}
+/* comb.c PetscCommSplitReductionBegin: start the (non-blocking) reduction now.  The local kernels are in flight since their Begin; the
+   ranks meet at the first End. */
+extern "C" PetscErrorCode PetscCommSplitReductionBegin(PetscComm comm) { if (!comm) SETERRQ(PETSC_ERR_ARG_NULL, "PetscCommSplitReductionBegin: null communicator"); return 0; }
+
 extern "C" PetscErrorCode VecNorm(Vec x, NormType type, PetscReal *val)
 {
   VecCheckReady(x, "VecNorm");
@@ -2209,7 +2312,7 @@ static PetscErrorCode ksp_free_work(KSP k)
 extern "C" PetscErrorCode KSPSetType(KSP k, const char *type)
 {
   if (!k || !type) SETERRQ(PETSC_ERR_ARG_NULL, "KSPSetType: null argument");
-  if (strcmp(type, KSPCG) && strcmp(type, KSPGMRES)) SETERRQ(PETSC_ERR_ARG_UNKNOWN_TYPE, "Unable to find requested KSP type %s", type);
+  if (strcmp(type, KSPCG) && strcmp(type, KSPGMRES) && strcmp(type, KSPPIPECG)) SETERRQ(PETSC_ERR_ARG_UNKNOWN_TYPE, "Unable to find requested KSP type %s", type);
   if (k->type != type) { PetscErrorCode ierr = ksp_free_work(k); CHKERRQ(ierr); }
   k->type = type;
   return 0;
@@ -2276,8 +2379,8 @@ extern "C" PetscErrorCode KSPSetUp(KSP k)
   if (k->normtype == KSP_NORM_DEFAULT) k->normtype = KSP_NORM_PRECONDITIONED; /* CG cg.c:424, GMRES gmres.c:915: left PC, preconditioned norm */
   if (k->pc->type.empty()) { ierr = PCSetType(k->pc, PCJACOBI); CHKERRQ(ierr); }
   if (!k->setup) {
-    if (k->type == KSPCG) { /* KSPSetUp_CG cg.c:56-80: 3 work vectors (+2 for single reduction) */
-      const PetscInt nwork = k->singlereduction ? 5 : 3;
+    if (k->type == KSPCG || k->type == KSPPIPECG) { /* KSPSetUp_CG cg.c:56-80: 3 work vectors (+2 for single reduction); KSPSetUp_PIPECG pipecg.c:13-20: 9 */
+      const PetscInt nwork = k->type == KSPPIPECG ? 9 : (k->singlereduction ? 5 : 3);
       Vec           *w;
       ierr = VecDuplicateVecs(k->vec_sol, nwork, &w); CHKERRQ(ierr);
       k->work.assign(w, w + nwork);
@@ -2425,6 +2528,98 @@ static PetscErrorCode KSPSolve_CG(KSP ksp)
     i++;
   } while (i < ksp->max_it);
   if (i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS;                                                          /* :276 */
+  return 0;
+}
+
+/* KSPSolve_PIPECG src/ksp/ksp/impls/cg/pipecg/pipecg.c:31-169 (Ghysels & Vanroose): one reduction per iteration (gamma, delta and the
+   norm queued together, comb.c), begun before PCApply and MatMult and collected after them.  On the GPU the three local kernels are
+   launched first, PCApply and MatMult are queued behind them, and the host collects the sums while those still run: the device never
+   waits for the host.  The price is 4 more vector updates per iteration than KSPCG. */
+static PetscErrorCode KSPSolve_PIPECG(KSP ksp)
+{
+  PetscErrorCode ierr;
+  PetscInt       i;
+  PetscScalar    alpha = 0.0, beta = 0.0, gamma = 0.0, gammaold = 0.0, delta = 0.0;
+  PetscReal      dp = 0.0;
+  Vec            X = ksp->vec_sol, B = ksp->vec_rhs, M = ksp->work[0], Z = ksp->work[1], P = ksp->work[2], N = ksp->work[3], W = ksp->work[4],
+                 Q = ksp->work[5], U = ksp->work[6], R = ksp->work[7], S = ksp->work[8];
+  Mat            Amat = ksp->amat;
+  PetscComm      comm = X->comm;
+  ksp->its = 0;
+  if (!ksp->guess_zero) { ierr = MatMult(Amat, X, R); CHKERRQ(ierr); ierr = VecAYPX(R, -1.0, B); CHKERRQ(ierr); } /* :62-63 */
+  else { ierr = VecCopy(B, R); CHKERRQ(ierr); }                                                                  /* :65 */
+  ierr = PCApply(ksp->pc, R, U); CHKERRQ(ierr);                                                                  /* :68 */
+  switch (ksp->normtype) {
+  case KSP_NORM_PRECONDITIONED:
+    ierr = VecNormBegin(U, NORM_2, &dp); CHKERRQ(ierr);                                                          /* :72 */
+    ierr = PetscCommSplitReductionBegin(comm); CHKERRQ(ierr);
+    ierr = MatMult(Amat, U, W); CHKERRQ(ierr);
+    ierr = VecNormEnd(U, NORM_2, &dp); CHKERRQ(ierr);
+    break;
+  case KSP_NORM_UNPRECONDITIONED:
+    ierr = VecNormBegin(R, NORM_2, &dp); CHKERRQ(ierr);                                                          /* :78 */
+    ierr = PetscCommSplitReductionBegin(comm); CHKERRQ(ierr);
+    ierr = MatMult(Amat, U, W); CHKERRQ(ierr);
+    ierr = VecNormEnd(R, NORM_2, &dp); CHKERRQ(ierr);
+    break;
+  case KSP_NORM_NATURAL:
+    ierr = VecDotBegin(R, U, &gamma); CHKERRQ(ierr);                                                             /* :84 */
+    ierr = PetscCommSplitReductionBegin(comm); CHKERRQ(ierr);
+    ierr = MatMult(Amat, U, W); CHKERRQ(ierr);
+    ierr = VecDotEnd(R, U, &gamma); CHKERRQ(ierr);
+    KSPCheckDot(ksp, gamma);
+    dp = sqrt(fabs(gamma));
+    break;
+  case KSP_NORM_NONE:
+    ierr = MatMult(Amat, U, W); CHKERRQ(ierr);
+    dp = 0.0;
+    break;
+  default: SETERRQ(PETSC_ERR_SUP, "KSPSolve_PIPECG: unsupported norm type %d", (int)ksp->normtype);
+  }
+  KSPLogResidualHistory(ksp, dp);
+  ksp->rnorm = dp;
+  ierr = KSPConvergedDefault(ksp, 0, dp, &ksp->reason); CHKERRQ(ierr);                                           /* :101 */
+  if (ksp->reason) return 0;
+  i = 0;
+  do {
+    if (i > 0 && ksp->normtype == KSP_NORM_UNPRECONDITIONED) { ierr = VecNormBegin(R, NORM_2, &dp); CHKERRQ(ierr); }       /* :106-110 */
+    else if (i > 0 && ksp->normtype == KSP_NORM_PRECONDITIONED) { ierr = VecNormBegin(U, NORM_2, &dp); CHKERRQ(ierr); }
+    if (!(i == 0 && ksp->normtype == KSP_NORM_NATURAL)) { ierr = VecDotBegin(R, U, &gamma); CHKERRQ(ierr); }               /* :111-113 */
+    ierr = VecDotBegin(W, U, &delta); CHKERRQ(ierr);                                                             /* :114 */
+    ierr = PetscCommSplitReductionBegin(comm); CHKERRQ(ierr);
+    ierr = PCApply(ksp->pc, W, M); CHKERRQ(ierr);                                                                /* :117 */
+    ierr = MatMult(Amat, M, N); CHKERRQ(ierr);                                                                   /* :118 */
+    if (i > 0 && ksp->normtype == KSP_NORM_UNPRECONDITIONED) { ierr = VecNormEnd(R, NORM_2, &dp); CHKERRQ(ierr); }
+    else if (i > 0 && ksp->normtype == KSP_NORM_PRECONDITIONED) { ierr = VecNormEnd(U, NORM_2, &dp); CHKERRQ(ierr); }
+    if (!(i == 0 && ksp->normtype == KSP_NORM_NATURAL)) { ierr = VecDotEnd(R, U, &gamma); CHKERRQ(ierr); }
+    ierr = VecDotEnd(W, U, &delta); CHKERRQ(ierr);
+    if (i > 0) {
+      if (ksp->normtype == KSP_NORM_NATURAL) dp = sqrt(fabs(gamma));
+      else if (ksp->normtype == KSP_NORM_NONE) dp = 0.0;
+      ksp->rnorm = dp;
+      KSPLogResidualHistory(ksp, dp);
+      ierr = KSPConvergedDefault(ksp, i, dp, &ksp->reason); CHKERRQ(ierr);                                       /* :137 */
+      if (ksp->reason) break;
+    }
+    if (i == 0) {
+      alpha = gamma / delta;
+      ierr = VecCopy(N, Z); CHKERRQ(ierr); ierr = VecCopy(M, Q); CHKERRQ(ierr);                                  /* :143-146 */
+      ierr = VecCopy(U, P); CHKERRQ(ierr); ierr = VecCopy(W, S); CHKERRQ(ierr);
+    } else {
+      beta = gamma / gammaold;
+      alpha = gamma / (delta - beta / alpha * gamma);                                                            /* :149 */
+      ierr = VecAYPX(Z, beta, N); CHKERRQ(ierr); ierr = VecAYPX(Q, beta, M); CHKERRQ(ierr);                      /* :150-153 */
+      ierr = VecAYPX(P, beta, U); CHKERRQ(ierr); ierr = VecAYPX(S, beta, W); CHKERRQ(ierr);
+    }
+    ierr = VecAXPY(X, alpha, P); CHKERRQ(ierr);                                                                  /* :155-158 */
+    ierr = VecAXPY(U, -alpha, Q); CHKERRQ(ierr);
+    ierr = VecAXPY(W, -alpha, Z); CHKERRQ(ierr);
+    ierr = VecAXPY(R, -alpha, S); CHKERRQ(ierr);
+    gammaold = gamma;
+    i++;
+    ksp->its = i;
+  } while (i < ksp->max_it);
+  if (i >= ksp->max_it) ksp->reason = KSP_DIVERGED_ITS;
   return 0;
 }
 
@@ -2599,7 +2794,9 @@ extern "C" PetscErrorCode KSPSolve(KSP ksp, Vec b, Vec x)
   if (ksp->guess_zero) { ierr = VecSet(x, 0.0); CHKERRQ(ierr); } /* itfunc.c:580 */
   ksp->hist_len = 0;
   ksp->reason = KSP_CONVERGED_ITERATING;
-  if (ksp->type == KSPCG) ierr = KSPSolve_CG(ksp); else ierr = KSPSolve_GMRES(ksp);
+  if (ksp->type == KSPCG) ierr = KSPSolve_CG(ksp);
+  else if (ksp->type == KSPPIPECG) ierr = KSPSolve_PIPECG(ksp);
+  else ierr = KSPSolve_GMRES(ksp);
   CHKERRQ(ierr);
   if (!ksp->reason) SETERRQ(PETSC_ERR_LIB, "Internal error, solver returned without setting converged reason"); /* itfunc.c:607 */
   return 0;

@@ -364,8 +364,9 @@ static int reduce_grid(int32_t n) { return phip_grid_for((int64_t)n / 2 + 1, 4, 
 
 /* One reduction: results into d_out[0..nres); when publish != 0 also into the pinned slot, with sequence number *seq_out */
 static int reduce_launch(phip_ctx c, int kind, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *d_out, int publish,
-                         unsigned long long *seq_out)
+                         unsigned long long *seq_out, const RedCtl *pub = NULL)
 {
+  /* pub: publish into that slot / sequence word (a by-product ticket) instead of the context's blocking-call slot */
   const int grid = reduce_grid(n);
   RedCtl    ctl;
   ctl.partial = c->d_partials; ctl.ticket = c->d_ticket; ctl.d_out = d_out; ctl.h_slot = NULL; ctl.h_seq = NULL; ctl.seq = 0; ctl.npub = 0; ctl.kofs = 0; ctl.accumulate = 0;
@@ -379,7 +380,10 @@ static int reduce_launch(phip_ctx c, int kind, int32_t n, const double *d_x, int
       MVPack    P;
       for (int k = 0; k < MV_MAX; k++) { P.y[k] = (k < g) ? h_dy[k0 + k] : d_x; P.a[k] = 0.0; }
       ctl.kofs = k0;
-      if (publish && k0 + g == nv) { ctl.h_slot = c->h_slot_dev; ctl.h_seq = c->h_seq_dev; ctl.seq = ++c->seq; ctl.npub = nv; *seq_out = ctl.seq; }
+      if (publish && k0 + g == nv) {
+        if (pub) { ctl.h_slot = pub->h_slot; ctl.h_seq = pub->h_seq; ctl.seq = pub->seq; ctl.npub = nv; }
+        else { ctl.h_slot = c->h_slot_dev; ctl.h_seq = c->h_seq_dev; ctl.seq = ++c->seq; ctl.npub = nv; *seq_out = ctl.seq; }
+      }
       switch (g) {
 #define MDOT_CASE(N) case N: launch_mdot<N>(c, n, d_x, P, ctl, grid); break;
         MDOT_CASE(1) MDOT_CASE(2) MDOT_CASE(3) MDOT_CASE(4) MDOT_CASE(5) MDOT_CASE(6) MDOT_CASE(7) MDOT_CASE(8)
@@ -392,7 +396,10 @@ static int reduce_launch(phip_ctx c, int kind, int32_t n, const double *d_x, int
     }
     return 0;
   }
-  if (publish) { ctl.h_slot = c->h_slot_dev; ctl.h_seq = c->h_seq_dev; ctl.seq = ++c->seq; ctl.npub = (kind == 4) ? 2 : 1; *seq_out = ctl.seq; }
+  if (publish) {
+    if (pub) { ctl.h_slot = pub->h_slot; ctl.h_seq = pub->h_seq; ctl.seq = pub->seq; ctl.npub = (kind == 4) ? 2 : 1; }
+    else { ctl.h_slot = c->h_slot_dev; ctl.h_seq = c->h_seq_dev; ctl.seq = ++c->seq; ctl.npub = (kind == 4) ? 2 : 1; *seq_out = ctl.seq; }
+  }
   switch (kind) {
   case 1: hipLaunchKernelGGL((norm_kernel<1>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, ctl); break;
   case 2: hipLaunchKernelGGL((norm_kernel<2>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, ctl); break;
@@ -434,6 +441,21 @@ extern "C" int phip_vec_reduce_local_host(phip_ctx c, int kind, int32_t n, const
     if (nv == 0) return 0;
   }
   return reduce_to_host(c, kind, n, d_x, nv, h_dy, kind == 0 ? nv : (kind == 4 ? 2 : 1), h_out);
+}
+
+/* The local part of a reduction launched WITHOUT waiting (VecDotBegin / VecNormBegin / VecMDotBegin, src/vec/vec/utils/comb.c): the
+   raw sums land in a by-product ticket; phip_ticket_wait fetches them later, after other work has been queued behind the launch. */
+extern "C" int phip_vec_reduce_begin(phip_ctx c, int kind, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, phip_ticket *t)
+{
+  CHECK_CTX(c, "phip_vec_reduce_begin"); CHECK_N(n, "phip_vec_reduce_begin");
+  PHIP_REQUIRE(t, PHIP_ERR_ARG_NULL, "phip_vec_reduce_begin: null ticket");
+  PHIP_REQUIRE(kind >= 0 && kind <= 4, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_reduce_begin: kind %d", kind);
+  const int nres = kind == 0 ? nv : (kind == 4 ? 2 : 1);
+  PHIP_REQUIRE(nres >= 1 && nres < PHIP_RING_VALS, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_reduce_begin: %d results (1..%d per call)", nres, PHIP_RING_VALS - 1);
+  RedCtl pub;
+  int    rc = phip_ticket_open(c, nres, 1, t, &pub);
+  if (rc) return rc;
+  return reduce_launch(c, kind, n, d_x, nv, h_dy, pub.d_out, 1, NULL, &pub);
 }
 
 extern "C" int phip_vec_dot(phip_ctx c, int32_t n, const double *d_x, const double *d_y, double *h_z)

@@ -341,6 +341,21 @@ class Vec:
         chk(lib().VecResetArray(self.h))
         self._placed = None
 
+    # split reductions (comb.c): begin ... other work ... end, in the same order
+    def dot_begin(self, y): chk(lib().VecDotBegin(self.h, y.h, None))
+
+    def dot_end(self, y):
+        z = C.c_double()
+        chk(lib().VecDotEnd(self.h, y.h, C.byref(z)))
+        return z.value
+
+    def norm_begin(self, ntype=NORM_2): chk(lib().VecNormBegin(self.h, ntype, None))
+
+    def norm_end(self, ntype=NORM_2):
+        z = (C.c_double * 2)()
+        chk(lib().VecNormEnd(self.h, ntype, z))
+        return (z[0], z[1]) if ntype == NORM_1_AND_2 else z[0]
+
     def mtdot(self, ys):
         arr = (C.c_void_p * max(len(ys), 1))(*[y.h for y in ys])
         z = np.zeros(len(ys))

@@ -446,6 +446,45 @@ def test_reductions_device_route(orc, size):
     np.testing.assert_allclose(host[0][1], dev[0][1], rtol=1e-13)
 
 
+@pytest.mark.parametrize("size", [1, 2, 3])
+def test_split_reductions_and_pipecg(orc, size):
+    """VecDotBegin/End, VecNormBegin/End (src/vec/vec/utils/comb.c) return what the blocking calls return, in Begin order, with other
+    work queued in between; KSPPIPECG (pipecg.c:31-169) follows the oracle's restatement: +-1 iteration, 1e-10 relative residual."""
+    from petsc_amd import generators as G, petsc as P
+    sym = G.laplace3d_7pt(13, dirichlet_rows=False)
+    n = len(sym[0]) - 1
+    bs = orc.operator(*sym, 1).mult(np.ones(n))
+    xg, yg = np.linspace(-1.0, 2.0, n), np.cos(np.arange(n))
+
+    def body(comm):
+        rs, re = local_slice(comm, n)
+        x = P.Vec.from_array(comm, xg[rs:re], n)
+        y = P.Vec.from_array(comm, yg[rs:re], n)
+        w = x.duplicate()
+        blocking = [x.dot(y), x.norm(), y.norm(P.NORM_1), y.norm(P.NORM_INFINITY), x.norm(P.NORM_1_AND_2), y.dot(y)]
+        x.dot_begin(y); x.norm_begin(); y.norm_begin(P.NORM_1); y.norm_begin(P.NORM_INFINITY); x.norm_begin(P.NORM_1_AND_2); y.dot_begin(y)
+        w.waxpy(2.0, x, y)   # work queued behind the reduction kernels
+        split = [x.dot_end(y), x.norm_end(), y.norm_end(P.NORM_1), y.norm_end(P.NORM_INFINITY), x.norm_end(P.NORM_1_AND_2), y.dot_end(y)]
+        # a second round reuses the queue; ending in another order is an error (comb.c)
+        x.dot_begin(y); y.norm_begin()
+        with pytest.raises(P.PetscError):
+            y.norm_end()
+        assert x.dot_end(y) == blocking[0] and y.norm_end() == np.sqrt(blocking[5])
+        out = [blocking, split, w.array()]
+        for nt in (P.KSP_NORM_PRECONDITIONED, P.KSP_NORM_UNPRECONDITIONED, P.KSP_NORM_NATURAL):
+            out.append(ksp_case(comm, *sym, bs, "pipecg", rtol=1e-9, normtype=nt))
+        for v in (x, y, w):
+            v.destroy()
+        return out
+
+    res = run_ranks(size, body)
+    assert res[0][0] == res[0][1]                      # the same kernels, the same order of sums: the same bits
+    np.testing.assert_array_equal(gather([r[2] for r in res]), orc.waxpy(2.0, xg, yg))
+    for k, nt in enumerate((1, 2, 3)):
+        ref = orc.operator(*sym, size).solve(bs, "pipecg", "jacobi", rtol=1e-9, normtype=nt)
+        check_ksp([r[3 + k] for r in res], ref)
+
+
 def test_cg_variants(orc):
     """norm types (cg.c:136-160), -ksp_cg_single_reduction (cg.c:226-243), non-zero initial guess (cg.c:131-132)."""
     from petsc_amd import generators as G, petsc as P
