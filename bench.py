@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="lap7_128")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--ksp", default="cg", choices=["cg", "pipecg"], help="developer switch; the judged metric is KSPCG")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     a = ap.parse_args()
@@ -119,7 +120,7 @@ def main():
     x, b = A.create_vecs()
     x.set(1.0)
     A.mult(x, b)  # b = A * 1
-    ksp = P.KSP(comm, "cg", "jacobi")
+    ksp = P.KSP(comm, a.ksp, "jacobi")
     ksp.set_operators(A)
 
     def run(its):
