@@ -12,7 +12,10 @@
 
 #define PHIP_RING 64
 #define PHIP_RING_VALS 8
-struct phip_ring_slot { unsigned long long seq; double vals[PHIP_RING_VALS - 1]; }; /* 64 bytes */
+/* Results cross to the host as FLAGGED WORDS: a double travels as two 8-byte words, each carrying 32 bits of the value and the 32-bit
+   sequence flag of the call.  An aligned 8-byte store is atomic, so a word whose flag matches holds valid data: no fence, no separate
+   sequence word, one PCIe write round instead of two (the low-latency protocol collective libraries use for small messages). */
+struct phip_ring_slot { unsigned long long ll[2 * PHIP_RING_VALS]; }; /* 128 bytes */
 
 struct phip_ctx_s {
   int          device;
@@ -23,10 +26,9 @@ struct phip_ctx_s {
   double      *d_result;    // [PHIP_MAX_MVEC] final reduction results (device)
   double      *h_result;    // pinned host mirror of d_result
   unsigned int *d_ticket;   // arrival counter of the fused reduction tail (zero between launches)
-  double      *h_slot;      // pinned, device-visible: results published by the last workgroup of a reduction
-  double      *h_slot_dev;  // device address of h_slot
-  unsigned long long *h_seq, *h_seq_dev; // sequence word the host spins on
-  unsigned long long  seq;  // last sequence number issued
+  unsigned long long *h_ll;     // pinned, device-visible: flagged words [2*PHIP_MAX_MVEC] published by the last workgroup of a reduction
+  unsigned long long *h_ll_dev; // device address of h_ll
+  unsigned long long  seq;  // last sequence number issued (its low 32 bits, never 0, are the flag)
   /* by-product reductions (phip_ticket): ring of result slots, device side and pinned host side */
   double      *d_ring;      // [PHIP_RING][PHIP_RING_VALS]
   struct phip_ring_slot *h_ring, *h_ring_dev; // [PHIP_RING]
@@ -38,8 +40,10 @@ struct phip_ctx_s {
 };
 
 /* profiling records (phip_runtime.hip): kind 0 = MatMult launches, 1 = MatMultAdd launches */
-/* wait until the device has published sequence number seq into c->h_seq (spin, with a periodic stream health check) */
-int phip_wait_seq(phip_ctx c, unsigned long long seq);
+/* wait until n flagged values with sequence number seq have arrived in ll (spin, with a periodic stream health check); copies them out */
+int phip_wait_ll(phip_ctx c, const unsigned long long *ll, int n, unsigned long long seq, double *out, const char *what);
+/* next sequence number whose low 32 bits are not 0 (0 is what untouched slot memory holds) */
+static inline unsigned long long phip_next_seq(unsigned long long *s) { if (!(unsigned int)(++*s)) ++*s; return *s; }
 
 /* by-product tickets (phip_runtime.hip): fill a RedCtl for a kernel that leaves nvals results in a fresh ring slot */
 struct RedCtl;

@@ -6,13 +6,20 @@ struct RedCtl {
   double             *partial; /* [PHIP_MAX_MVEC][PHIP_RED_BLOCKS] */
   unsigned int       *ticket;  /* arrival counters [PHIP_RED_BLOCKS/32 + 1][32] (one used word per 128-byte line), zero on entry and on exit */
   double             *d_out;   /* device results, indexed like the partial rows */
-  double             *h_slot;  /* pinned host slot (device address) or NULL: publish d_out[0..npub) there ... */
-  unsigned long long *h_seq;   /* ... then store seq here */
-  unsigned long long  seq;
+  unsigned long long *h_ll;    /* pinned host slot (device address) or NULL: publish d_out[0..npub) there as flagged words ... */
+  unsigned long long  seq;     /* ... whose flag is the low 32 bits of seq */
   int                 npub;
   int                 kofs;    /* first partial row / d_out index of this launch */
   int                 accumulate; /* add to d_out[] (written by an earlier kernel of the stream) instead of overwriting it */
 };
+
+/* value k of a result slot, as two flagged 8-byte words (phip_internal.h) */
+__device__ __forceinline__ void publish_ll(unsigned long long *ll, int k, double v, unsigned long long seq)
+{
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(v), flag = (seq & 0xFFFFFFFFull) << 32;
+  __hip_atomic_store(&ll[2 * k], flag | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&ll[2 * k + 1], flag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -93,7 +100,11 @@ __device__ __forceinline__ void reduce_tail(double (&acc)[NV], double *lds /* >=
         }
       }
       m = wave_max(m); f = wave_max(f);
-      if (lane == 0) c.d_out[c.kofs] = (f > 0.0) ? __builtin_nan("") : m;
+      if (lane == 0) {
+        const double r = (f > 0.0) ? __builtin_nan("") : m;
+        c.d_out[c.kofs] = r;
+        if (c.h_ll && c.kofs < c.npub) publish_ll(c.h_ll, c.kofs, r, c.seq);
+      }
     }
   } else {
     for (int k = w; k < NV; k += PHIP_THREADS / 64) {
@@ -110,19 +121,13 @@ __device__ __forceinline__ void reduce_tail(double (&acc)[NV], double *lds /* >=
         for (int j = 0; j < 16; j++) s += v[j];
       }
       s = wave_sum(s);
-      if (lane == 0) c.d_out[c.kofs + k] = c.accumulate ? c.d_out[c.kofs + k] + s : s;
+      if (lane == 0) { /* the result goes to the host straight from the register: no round trip through d_out */
+        const double r = c.accumulate ? c.d_out[c.kofs + k] + s : s;
+        c.d_out[c.kofs + k] = r;
+        if (c.h_ll && c.kofs + k < c.npub) publish_ll(c.h_ll, c.kofs + k, r, c.seq);
+      }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (t == 0) {
-    if (c.h_slot) {
-      /* d_out[0..kofs) came from earlier launches of the same call (earlier kernels on this stream), the rest from the stores above */
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      for (int k = 0; k < c.npub; k++) c.h_slot[k] = __hip_atomic_load(&c.d_out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence_system();
-      __hip_atomic_store(c.h_seq, c.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
+  /* results of earlier launches of the same call (the first groups of a long VecMDot) ride along: written by earlier kernels of the stream */
+  if (c.h_ll && t < c.kofs && t < c.npub) publish_ll(c.h_ll, t, c.d_out[t], c.seq);
 }
-

@@ -53,11 +53,10 @@ extern "C" int phip_init(int device, phip_ctx *out)
   PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_result, sizeof(double) * PHIP_MAX_MVEC, hipHostMallocDefault));
   PHIP_CHECK_HIP(hipMalloc((void **)&c->d_ticket, 4 * 32 * (PHIP_RED_BLOCKS / 32 + 1)));
   PHIP_CHECK_HIP(hipMemsetAsync(c->d_ticket, 0, 4 * 32 * (PHIP_RED_BLOCKS / 32 + 1), c->stream));
-  PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_slot, sizeof(double) * PHIP_MAX_MVEC, hipHostMallocMapped | hipHostMallocCoherent));
-  PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_seq, 64, hipHostMallocMapped | hipHostMallocCoherent));
-  PHIP_CHECK_HIP(hipHostGetDevicePointer((void **)&c->h_slot_dev, c->h_slot, 0));
-  PHIP_CHECK_HIP(hipHostGetDevicePointer((void **)&c->h_seq_dev, c->h_seq, 0));
-  *c->h_seq = 0; c->seq = 0;
+  PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_ll, sizeof(unsigned long long) * 2 * PHIP_MAX_MVEC, hipHostMallocMapped | hipHostMallocCoherent));
+  PHIP_CHECK_HIP(hipHostGetDevicePointer((void **)&c->h_ll_dev, c->h_ll, 0));
+  memset(c->h_ll, 0, sizeof(unsigned long long) * 2 * PHIP_MAX_MVEC);
+  c->seq = 0;
   PHIP_CHECK_HIP(hipMalloc((void **)&c->d_ring, sizeof(double) * PHIP_RING * PHIP_RING_VALS));
   PHIP_CHECK_HIP(hipMemsetAsync(c->d_ring, 0, sizeof(double) * PHIP_RING * PHIP_RING_VALS, c->stream));
   PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_ring, sizeof(phip_ring_slot) * PHIP_RING, hipHostMallocMapped | hipHostMallocCoherent));
@@ -79,7 +78,7 @@ extern "C" int phip_finalize(phip_ctx c)
   PHIP_CHECK_HIP(hipSetDevice(c->device));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->comm_stream));
-  hipFree(c->d_ticket); hipHostFree(c->h_slot); hipHostFree(c->h_seq); hipFree(c->d_ring); hipHostFree(c->h_ring);
+  hipFree(c->d_ticket); hipHostFree(c->h_ll); hipFree(c->d_ring); hipHostFree(c->h_ring);
   hipFree(c->d_partials); hipFree(c->d_result); hipHostFree(c->h_result); hipFree(c->d_flag); hipHostFree(c->h_flag);
   if (c->prof) {
     for (int k = 0; k < 2; k++) for (int w = 0; w < 2; w++) for (hipEvent_t e : c->prof->ev[k][w]) hipEventDestroy(e);
@@ -172,33 +171,35 @@ extern "C" int phip_device_sync(phip_ctx c)
 
 extern "C" void *phip_stream(phip_ctx c) { return c ? (void *)c->stream : NULL; }
 
-/* copy n device scalars into the pinned slot and raise the sequence word: one tiny kernel instead of a copy + stream sync */
-__global__ void publish_kernel(const double *__restrict__ src, int n, double *slot, unsigned long long *seqw, unsigned long long seq)
+/* copy n device scalars into the pinned slot as flagged words: one tiny kernel instead of a copy + stream sync */
+__global__ void publish_kernel(const double *__restrict__ src, int n, unsigned long long *ll, unsigned long long seq)
 {
   const int t = threadIdx.x;
-  if (t < n) slot[t] = src[t];
-  __threadfence_system();
-  __syncthreads();
-  if (t == 0) __hip_atomic_store(seqw, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (t < n) publish_ll(ll, t, src[t], seq);
 }
 
-int phip_wait_seq(phip_ctx c, unsigned long long seq)
+int phip_wait_ll(phip_ctx c, const unsigned long long *ll, int n, unsigned long long seq, double *out, const char *what)
 {
-  volatile unsigned long long *p = c->h_seq;
-  for (unsigned long spin = 1;; spin++) {
-    if (*p == seq) break;
+  const unsigned long long flag = seq & 0xFFFFFFFFull;
+  int k = 0; /* words 0 .. 2n-1 arrive in any order; wait for them one after the other */
+  for (unsigned long spin = 1; k < 2 * n; spin++) {
+    const unsigned long long w = __atomic_load_n(&ll[k], __ATOMIC_RELAXED);
+    if ((w >> 32) == flag) { k++; continue; }
     if ((spin & 0x3FFF) == 0) { /* every ~16k polls: is the stream still healthy? */
       hipError_t e = hipStreamQuery(c->stream);
       if (e == hipSuccess) {
-        if (*p == seq) break;
-        phip_set_error("phip_wait_seq: the stream drained but result %llu was never published (have %llu)", seq, (unsigned long long)*p);
-        return PHIP_ERR_LIB;
+        if ((__atomic_load_n(&ll[k], __ATOMIC_RELAXED) >> 32) == flag) continue;
+        phip_set_error("%s: the stream drained but result %llu was never published (was the ticket opened without publish?)", what, seq);
+        return PHIP_ERR_ARG_WRONGSTATE;
       }
-      if (e != hipErrorNotReady) { phip_set_error("phip_wait_seq: %s", hipGetErrorString(e)); return PHIP_ERR_LIB; }
+      if (e != hipErrorNotReady) { phip_set_error("%s: %s", what, hipGetErrorString(e)); return PHIP_ERR_LIB; }
     }
     __builtin_ia32_pause();
   }
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  for (int i = 0; i < n; i++) {
+    const unsigned long long bits = (__atomic_load_n(&ll[2 * i], __ATOMIC_RELAXED) & 0xFFFFFFFFull) | (__atomic_load_n(&ll[2 * i + 1], __ATOMIC_RELAXED) << 32);
+    memcpy(&out[i], &bits, 8);
+  }
   return 0;
 }
 
@@ -208,13 +209,10 @@ extern "C" int phip_read_scalars(phip_ctx c, const double *d_src, int32_t n, dou
   PHIP_REQUIRE(n >= 0 && n <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_read_scalars: n=%d", n);
   PHIP_NEED_DEVICE(c, "phip_read_scalars");
   if (!n) { PHIP_CHECK_HIP(hipStreamSynchronize(c->stream)); return 0; }
-  const unsigned long long seq = ++c->seq;
-  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(PHIP_MAX_MVEC), 0, c->stream, d_src, n, c->h_slot_dev, c->h_seq_dev, seq);
+  const unsigned long long seq = phip_next_seq(&c->seq);
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(PHIP_MAX_MVEC), 0, c->stream, d_src, n, c->h_ll_dev, seq);
   PHIP_CHECK_HIP(hipGetLastError());
-  int rc = phip_wait_seq(c, seq);
-  if (rc) return rc;
-  for (int i = 0; i < n; i++) h_dst[i] = c->h_slot[i];
-  return 0;
+  return phip_wait_ll(c, c->h_ll, n, seq, h_dst, "phip_read_scalars");
 }
 
 extern "C" int phip_event_create(phip_ctx c, void **event)
@@ -305,12 +303,12 @@ extern "C" int phip_profile_read(phip_ctx c, int kind, int32_t *count, double *s
 int phip_ticket_open(phip_ctx c, int nvals, int publish, phip_ticket *t, RedCtl *ctl)
 {
   PHIP_REQUIRE(t && ctl && nvals >= 1 && nvals < PHIP_RING_VALS, PHIP_ERR_ARG_OUTOFRANGE, "phip_ticket_open: nvals %d", nvals);
-  const unsigned long long seq = ++c->ring_seq;
+  const unsigned long long seq = phip_next_seq(&c->ring_seq);
   const int                slot = (int)(seq % PHIP_RING);
   t->slot = slot; t->nvals = nvals; t->seq = seq;
   ctl->partial = c->d_partials; ctl->ticket = c->d_ticket; ctl->d_out = c->d_ring + (size_t)slot * PHIP_RING_VALS;
-  ctl->kofs = 0; ctl->accumulate = 0; ctl->npub = 0; ctl->h_slot = NULL; ctl->h_seq = NULL; ctl->seq = 0;
-  if (publish) { ctl->h_slot = c->h_ring_dev[slot].vals; ctl->h_seq = &c->h_ring_dev[slot].seq; ctl->seq = seq; ctl->npub = nvals; }
+  ctl->kofs = 0; ctl->accumulate = 0; ctl->npub = 0; ctl->h_ll = NULL; ctl->seq = 0;
+  if (publish) { ctl->h_ll = c->h_ring_dev[slot].ll; ctl->seq = seq; ctl->npub = nvals; }
   return 0;
 }
 
@@ -323,8 +321,8 @@ int phip_ticket_accumulate(phip_ctx c, const phip_ticket *t, int publish, RedCtl
 {
   PHIP_REQUIRE(ticket_live(c, t), PHIP_ERR_ARG_WRONGSTATE, "phip_ticket_accumulate: the ticket has expired");
   ctl->partial = c->d_partials; ctl->ticket = c->d_ticket; ctl->d_out = c->d_ring + (size_t)t->slot * PHIP_RING_VALS;
-  ctl->kofs = 0; ctl->accumulate = 1; ctl->npub = 0; ctl->h_slot = NULL; ctl->h_seq = NULL; ctl->seq = 0;
-  if (publish) { ctl->h_slot = c->h_ring_dev[t->slot].vals; ctl->h_seq = &c->h_ring_dev[t->slot].seq; ctl->seq = t->seq; ctl->npub = t->nvals; }
+  ctl->kofs = 0; ctl->accumulate = 1; ctl->npub = 0; ctl->h_ll = NULL; ctl->seq = 0;
+  if (publish) { ctl->h_ll = c->h_ring_dev[t->slot].ll; ctl->seq = t->seq; ctl->npub = t->nvals; }
   return 0;
 }
 
@@ -342,21 +340,5 @@ extern "C" int phip_ticket_wait(phip_ctx c, const phip_ticket *t, double *h_vals
   PHIP_REQUIRE(c && h_vals, PHIP_ERR_ARG_NULL, "phip_ticket_wait: null argument");
   PHIP_NEED_DEVICE(c, "phip_ticket_wait");
   PHIP_REQUIRE(ticket_live(c, t), PHIP_ERR_ARG_WRONGSTATE, "phip_ticket_wait: the ticket has expired");
-  volatile unsigned long long *p = &c->h_ring[t->slot].seq;
-  for (unsigned long spin = 1;; spin++) {
-    if (*p == t->seq) break;
-    if ((spin & 0x3FFF) == 0) {
-      hipError_t e = hipStreamQuery(c->stream);
-      if (e == hipSuccess) {
-        if (*p == t->seq) break;
-        phip_set_error("phip_ticket_wait: the stream drained but ticket %llu was never published (was it opened without publish?)", t->seq);
-        return PHIP_ERR_ARG_WRONGSTATE;
-      }
-      if (e != hipErrorNotReady) { phip_set_error("phip_ticket_wait: %s", hipGetErrorString(e)); return PHIP_ERR_LIB; }
-    }
-    __builtin_ia32_pause();
-  }
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  for (int i = 0; i < t->nvals; i++) h_vals[i] = c->h_ring[t->slot].vals[i];
-  return 0;
+  return phip_wait_ll(c, c->h_ring[t->slot].ll, t->nvals, t->seq, h_vals, "phip_ticket_wait");
 }

@@ -369,7 +369,7 @@ static int reduce_launch(phip_ctx c, int kind, int32_t n, const double *d_x, int
   /* pub: publish into that slot / sequence word (a by-product ticket) instead of the context's blocking-call slot */
   const int grid = reduce_grid(n);
   RedCtl    ctl;
-  ctl.partial = c->d_partials; ctl.ticket = c->d_ticket; ctl.d_out = d_out; ctl.h_slot = NULL; ctl.h_seq = NULL; ctl.seq = 0; ctl.npub = 0; ctl.kofs = 0; ctl.accumulate = 0;
+  ctl.partial = c->d_partials; ctl.ticket = c->d_ticket; ctl.d_out = d_out; ctl.h_ll = NULL; ctl.seq = 0; ctl.npub = 0; ctl.kofs = 0; ctl.accumulate = 0;
   if (kind == 0) {
     PHIP_REQUIRE(nv >= 0 && nv <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_reduce_local: nv=%d (max %d)", nv, PHIP_MAX_MVEC);
     PHIP_REQUIRE(h_dy || !nv, PHIP_ERR_ARG_NULL, "phip_vec_reduce_local: null vector list");
@@ -381,8 +381,8 @@ static int reduce_launch(phip_ctx c, int kind, int32_t n, const double *d_x, int
       for (int k = 0; k < MV_MAX; k++) { P.y[k] = (k < g) ? h_dy[k0 + k] : d_x; P.a[k] = 0.0; }
       ctl.kofs = k0;
       if (publish && k0 + g == nv) {
-        if (pub) { ctl.h_slot = pub->h_slot; ctl.h_seq = pub->h_seq; ctl.seq = pub->seq; ctl.npub = nv; }
-        else { ctl.h_slot = c->h_slot_dev; ctl.h_seq = c->h_seq_dev; ctl.seq = ++c->seq; ctl.npub = nv; *seq_out = ctl.seq; }
+        if (pub) { ctl.h_ll = pub->h_ll; ctl.seq = pub->seq; ctl.npub = nv; }
+        else { ctl.h_ll = c->h_ll_dev; ctl.seq = phip_next_seq(&c->seq); ctl.npub = nv; *seq_out = ctl.seq; }
       }
       switch (g) {
 #define MDOT_CASE(N) case N: launch_mdot<N>(c, n, d_x, P, ctl, grid); break;
@@ -397,8 +397,8 @@ static int reduce_launch(phip_ctx c, int kind, int32_t n, const double *d_x, int
     return 0;
   }
   if (publish) {
-    if (pub) { ctl.h_slot = pub->h_slot; ctl.h_seq = pub->h_seq; ctl.seq = pub->seq; ctl.npub = (kind == 4) ? 2 : 1; }
-    else { ctl.h_slot = c->h_slot_dev; ctl.h_seq = c->h_seq_dev; ctl.seq = ++c->seq; ctl.npub = (kind == 4) ? 2 : 1; *seq_out = ctl.seq; }
+    if (pub) { ctl.h_ll = pub->h_ll; ctl.seq = pub->seq; ctl.npub = (kind == 4) ? 2 : 1; }
+    else { ctl.h_ll = c->h_ll_dev; ctl.seq = phip_next_seq(&c->seq); ctl.npub = (kind == 4) ? 2 : 1; *seq_out = ctl.seq; }
   }
   switch (kind) {
   case 1: hipLaunchKernelGGL((norm_kernel<1>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, ctl); break;
@@ -424,9 +424,7 @@ static int reduce_to_host(phip_ctx c, int kind, int32_t n, const double *d_x, in
   unsigned long long seq = 0;
   int                rc = reduce_launch(c, kind, n, d_x, nv, h_dy, c->d_result, 1, &seq);
   if (rc) return rc;
-  if ((rc = phip_wait_seq(c, seq))) return rc;
-  for (int i = 0; i < nres; i++) r[i] = c->h_slot[i];
-  return 0;
+  return phip_wait_ll(c, c->h_ll, nres, seq, r, "reduction");
 }
 
 /* the local part of a distributed reduction, delivered to the HOST (one launch, pinned slot, spin): raw sums, no square root, so that
