@@ -272,6 +272,8 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
     const double  *xv = STAGE ? xs : x;
     double y0 = 0.0, y1 = 0.0;
     if (add && act) { y0 = yin[r0]; if (has1) y1 = yin[r0 + 1]; }
+    double dv0 = 0.0, dv1 = 0.0; /* the fused dot's weights: requested here so that their latency hides behind the row sums */
+    if (DOT && act) { dv0 = dotv[r0]; if (has1) dv1 = dotv[r0 + 1]; }
     double s0 = y0, s1 = y1;
     int    s = 0;
     for (; s + 4 <= lm; s += 4) {
@@ -301,8 +303,8 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
     if (has1) *reinterpret_cast<double2 *>(yout + r0) = make_double2(s0, s1);
     else if (act) yout[r0] = s0;
     if (DOT && act) {
-      dacc += dotv[r0] * (s0 - y0);
-      if (has1) dacc += dotv[r0 + 1] * (s1 - y1);
+      dacc += dv0 * (s0 - y0);
+      if (has1) dacc += dv1 * (s1 - y1);
     }
   }
   if (DOT) {
