@@ -60,6 +60,18 @@ def main():
 
     run("spmv", lambda: L.phip_mat_mult(A, dx, dy), 12 * nz + 20 * m + 4)
     run("spmv_add", lambda: L.phip_mat_multadd(A, dx, dy, dy), 12 * nz + 28 * m + 4)
+    import ctypes as C
+    from petsc_amd.capi import Ticket
+    tk = Ticket()
+    run("spmv+dot(async)", lambda: L.phip_mat_mult_dot(A, dx, dy, dx, 0, C.byref(tk)), 12 * nz + 28 * m + 4)
+    hv = (C.c_double * 8)()
+
+    def spmv_dot_sync():
+        L.phip_mat_mult_dot(A, dx, dy, dx, 1, C.byref(tk))
+        L.phip_ticket_wait(ctx.h, C.byref(tk), hv)
+    run("spmv+dot(sync)", spmv_dot_sync, 12 * nz + 28 * m + 4)
+    tw = Ticket()
+    run("pmult+3red(async)", lambda: L.phip_vec_pointwise_mult_reduce(ctx.h, m, dy, dx, dz, 0, C.byref(tw)), 24 * m)
     if a.vec:
         run("axpy", lambda: L.phip_vec_axpy(ctx.h, m, dy, 0.5, dx), 24 * m)
         run("aypx", lambda: L.phip_vec_aypx(ctx.h, m, dy, 0.5, dx), 24 * m)
