@@ -22,10 +22,10 @@ struct phip_ctx_s {
   int          cu_count;
   hipStream_t  stream;      // compute stream: all kernels, in call order
   hipStream_t  comm_stream; // ghost exchange, overlapped with the diagonal-block SpMV
-  double      *d_partials;  // [PHIP_MAX_MVEC][PHIP_RED_BLOCKS] block partials of reductions
+  unsigned long long *d_partials; // [PHIP_MAX_MVEC][PHIP_RED_BLOCKS][2] block partials of reductions, as flagged words
+  unsigned int pseq;        // flag of the last launch's partials
   double      *d_result;    // [PHIP_MAX_MVEC] final reduction results (device)
   double      *h_result;    // pinned host mirror of d_result
-  unsigned int *d_ticket;   // arrival counter of the fused reduction tail (zero between launches)
   unsigned long long *h_ll;     // pinned, device-visible: flagged words [2*PHIP_MAX_MVEC] published by the last workgroup of a reduction
   unsigned long long *h_ll_dev; // device address of h_ll
   unsigned long long  seq;  // last sequence number issued (its low 32 bits, never 0, are the flag)
@@ -44,6 +44,7 @@ struct phip_ctx_s {
 int phip_wait_ll(phip_ctx c, const unsigned long long *ll, int n, unsigned long long seq, double *out, const char *what);
 /* next sequence number whose low 32 bits are not 0 (0 is what untouched slot memory holds) */
 static inline unsigned long long phip_next_seq(unsigned long long *s) { if (!(unsigned int)(++*s)) ++*s; return *s; }
+static inline unsigned int phip_next_pflag(phip_ctx c) { if (!++c->pseq) ++c->pseq; return c->pseq; }
 
 /* by-product tickets (phip_runtime.hip): fill a RedCtl for a kernel that leaves nvals results in a fresh ring slot */
 struct RedCtl;

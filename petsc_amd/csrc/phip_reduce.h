@@ -3,8 +3,8 @@
 #include "phip_internal.h"
 
 struct RedCtl {
-  double             *partial; /* [PHIP_MAX_MVEC][PHIP_RED_BLOCKS] */
-  unsigned int       *ticket;  /* arrival counters [PHIP_RED_BLOCKS/32 + 1][32] (one used word per 128-byte line), zero on entry and on exit */
+  unsigned long long *partial; /* [PHIP_MAX_MVEC][PHIP_RED_BLOCKS][2] flagged words */
+  unsigned int        pflag;   /* flag of this launch's partials: unique per launch, never 0 */
   double             *d_out;   /* device results, indexed like the partial rows */
   unsigned long long *h_ll;    /* pinned host slot (device address) or NULL: publish d_out[0..npub) there as flagged words ... */
   unsigned long long  seq;     /* ... whose flag is the low 32 bits of seq */
@@ -52,77 +52,94 @@ __device__ __forceinline__ void block_sum(double (&acc)[NV], double *lds /* [4*N
   }
 }
 
-/* Tail of every reduction kernel.  acc[] holds the workgroup's partials in thread 0.  MODE 0: NV sums.  MODE 1: acc[0] = max,
-   acc[1] = NaN flag -> one result (NaN if any flag, bvec2.c:253-258). */
-template <int NV, int MODE>
-__device__ __forceinline__ void reduce_tail(double (&acc)[NV], double *lds /* >= 4 doubles */, const RedCtl c)
+/* one flagged value (two 8-byte words, value half + flag) in device memory, visible to every XCD */
+__device__ __forceinline__ void partial_put(unsigned long long *p, double v, unsigned int flag)
 {
-  __shared__ int s_last;
-  const int      t = threadIdx.x;
-  const int      nb = gridDim.x;
-  if (t == 0) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(v), f = (unsigned long long)flag << 32;
+  __hip_atomic_store(&p[0], f | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&p[1], f | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+/* B flagged values p[2*stride*j], j < B, all requested at once; the batch is requested again until every flag matches (entries i >= n
+   are skipped and read as 0).  *ok goes to 0 if they do not come (a workgroup that died): the caller then publishes NaN. */
+template <int B>
+__device__ __forceinline__ void partial_get_batch(const unsigned long long *p, int stride, int i0, int n, unsigned int flag, double (&v)[B], int *ok)
+{
+  unsigned long long w0[B], w1[B];
+  for (int spin = 0;; spin++) {
 #pragma unroll
-    for (int k = 0; k < NV; k++) __hip_atomic_store(&c.partial[(size_t)(c.kofs + k) * PHIP_RED_BLOCKS + blockIdx.x], acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    /* two-level arrival count: 32 workgroups per group counter (each on a 128-byte line of its own), then one top counter, so that
-       no word takes more than 32 serialised atomics (~12 ns each on one address); the last arrivers put the counters back to zero */
-    const int          g = blockIdx.x >> 5;
-    const unsigned int gsize = (unsigned int)((nb - (g << 5)) < 32 ? (nb - (g << 5)) : 32);
-    int                last = 0;
-    const unsigned int tk = __hip_atomic_fetch_add(&c.ticket[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tk == gsize - 1) {
-      __hip_atomic_store(&c.ticket[g * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned int ngroups = (unsigned int)((nb + 31) >> 5);
-      const unsigned int tk2 = __hip_atomic_fetch_add(&c.ticket[(PHIP_RED_BLOCKS / 32) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tk2 == ngroups - 1) {
-        __hip_atomic_store(&c.ticket[(PHIP_RED_BLOCKS / 32) * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = 1;
+    for (int j = 0; j < B; j++) {
+      const int i = i0 + stride * j;
+      if (i < n) {
+        w0[j] = __hip_atomic_load(&p[2 * (size_t)i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w1[j] = __hip_atomic_load(&p[2 * (size_t)i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    s_last = last;
+    bool all = true;
+#pragma unroll
+    for (int j = 0; j < B; j++)
+      if (i0 + stride * j < n) all = all && (unsigned int)(w0[j] >> 32) == flag && (unsigned int)(w1[j] >> 32) == flag;
+    if (all) break;
+    if (spin > (1 << 22)) { *ok = 0; break; } /* seconds: never in a healthy launch, and the kernel still ends */
+    __builtin_amdgcn_s_sleep(1);
   }
-  __syncthreads();
-  if (!s_last) return;
-  /* last workgroup: wave w sums partial rows w, w+4, ...: lane l adds the values l, l+64, l+128, ... in that order (16 loads in flight
-     at a time), then the 64-lane tree -- a fixed order for a given grid, whichever workgroup arrives last */
+#pragma unroll
+  for (int j = 0; j < B; j++) v[j] = (i0 + stride * j < n) ? __longlong_as_double((long long)((w0[j] & 0xFFFFFFFFull) | (w1[j] << 32))) : 0.0;
+}
+
+/* Tail of every reduction kernel.  acc[] holds the workgroup's partials in thread 0.  MODE 0: NV sums.  MODE 1: acc[0] = max,
+   acc[1] = NaN flag -> one result (NaN if any flag, bvec2.c:253-258).
+   Every workgroup leaves its partials as flagged words (the flag is unique to the launch) and is done.  The workgroup with the highest
+   index collects them: its lanes wait for the flags of the entries they sum -- no arrival counter, no store-acknowledge wait, no
+   atomics; the chain after the slowest workgroup's store is one load, the sum and the publication.  Workgroups are dispatched in
+   index order (per XCD), so every workgroup the collector waits for is running or finished when it starts to wait. */
+template <int NV, int MODE>
+__device__ __forceinline__ void reduce_tail(double (&acc)[NV], double *lds /* unused */, const RedCtl c)
+{
+  const int t = threadIdx.x;
+  const int nb = gridDim.x;
+  (void)lds;
+  if (t == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) partial_put(c.partial + 2 * ((size_t)(c.kofs + k) * PHIP_RED_BLOCKS + blockIdx.x), acc[k], c.pflag);
+  }
+  if ((int)blockIdx.x != nb - 1) return;
+  /* collector: wave w sums partial rows w, w+4, ...: lane l adds the values l, l+64, l+128, ... in that order (8 values requested at a
+     time), then the 64-lane tree -- a fixed order for a given grid */
   const int w = t >> 6, lane = t & 63;
+  int       ok = 1;
   if (MODE == 1) {
     if (w == 0) {
       double m = 0.0, f = 0.0;
-      for (int j0 = 0; j0 * 64 < nb; j0 += 16) {
+      for (int j0 = 0; j0 * 64 < nb; j0 += 8) {
+        double vm[8], vf[8];
+        partial_get_batch<8>(c.partial + 2 * ((size_t)c.kofs * PHIP_RED_BLOCKS), 64, lane + 64 * j0, nb, c.pflag, vm, &ok);
+        partial_get_batch<8>(c.partial + 2 * ((size_t)(c.kofs + 1) * PHIP_RED_BLOCKS), 64, lane + 64 * j0, nb, c.pflag, vf, &ok);
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-          const int i = lane + 64 * (j0 + j);
-          if (i < nb) {
-            m = fmax(m, __hip_atomic_load(&c.partial[(size_t)c.kofs * PHIP_RED_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            f = fmax(f, __hip_atomic_load(&c.partial[(size_t)(c.kofs + 1) * PHIP_RED_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          }
-        }
+        for (int j = 0; j < 8; j++) { m = fmax(m, vm[j]); f = fmax(f, vf[j]); }
       }
       m = wave_max(m); f = wave_max(f);
+      ok = __all(ok);
       if (lane == 0) {
-        const double r = (f > 0.0) ? __builtin_nan("") : m;
+        const double r = (f > 0.0 || !ok) ? __builtin_nan("") : m;
         c.d_out[c.kofs] = r;
         if (c.h_ll && c.kofs < c.npub) publish_ll(c.h_ll, c.kofs, r, c.seq);
       }
     }
   } else {
     for (int k = w; k < NV; k += PHIP_THREADS / 64) {
-      const double *row = c.partial + (size_t)(c.kofs + k) * PHIP_RED_BLOCKS;
-      double        s = 0.0;
-      for (int j0 = 0; j0 * 64 < nb; j0 += 16) {
-        double v[16];
+      const unsigned long long *row = c.partial + 2 * ((size_t)(c.kofs + k) * PHIP_RED_BLOCKS);
+      double                    s = 0.0;
+      for (int j0 = 0; j0 * 64 < nb; j0 += 8) {
+        double v[8];
+        partial_get_batch<8>(row, 64, lane + 64 * j0, nb, c.pflag, v, &ok);
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-          const int i = lane + 64 * (j0 + j);
-          v[j] = (i < nb) ? __hip_atomic_load(&row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; j++) s += v[j];
+        for (int j = 0; j < 8; j++) s += v[j];
       }
       s = wave_sum(s);
+      ok = __all(ok);
       if (lane == 0) { /* the result goes to the host straight from the register: no round trip through d_out */
-        const double r = c.accumulate ? c.d_out[c.kofs + k] + s : s;
+        double r = c.accumulate ? c.d_out[c.kofs + k] + s : s;
+        if (!ok) r = __builtin_nan("");
         c.d_out[c.kofs + k] = r;
         if (c.h_ll && c.kofs + k < c.npub) publish_ll(c.h_ll, c.kofs + k, r, c.seq);
       }

@@ -48,11 +48,11 @@ extern "C" int phip_init(int device, phip_ctx *out)
   c->cu_count = prop.multiProcessorCount;
   PHIP_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   PHIP_CHECK_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-  PHIP_CHECK_HIP(hipMalloc((void **)&c->d_partials, sizeof(double) * PHIP_MAX_MVEC * PHIP_RED_BLOCKS));
+  PHIP_CHECK_HIP(hipMalloc((void **)&c->d_partials, sizeof(unsigned long long) * 2 * PHIP_MAX_MVEC * PHIP_RED_BLOCKS));
+  PHIP_CHECK_HIP(hipMemsetAsync(c->d_partials, 0, sizeof(unsigned long long) * 2 * PHIP_MAX_MVEC * PHIP_RED_BLOCKS, c->stream));
+  c->pseq = 0;
   PHIP_CHECK_HIP(hipMalloc((void **)&c->d_result, sizeof(double) * PHIP_MAX_MVEC));
   PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_result, sizeof(double) * PHIP_MAX_MVEC, hipHostMallocDefault));
-  PHIP_CHECK_HIP(hipMalloc((void **)&c->d_ticket, 4 * 32 * (PHIP_RED_BLOCKS / 32 + 1)));
-  PHIP_CHECK_HIP(hipMemsetAsync(c->d_ticket, 0, 4 * 32 * (PHIP_RED_BLOCKS / 32 + 1), c->stream));
   PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_ll, sizeof(unsigned long long) * 2 * PHIP_MAX_MVEC, hipHostMallocMapped | hipHostMallocCoherent));
   PHIP_CHECK_HIP(hipHostGetDevicePointer((void **)&c->h_ll_dev, c->h_ll, 0));
   memset(c->h_ll, 0, sizeof(unsigned long long) * 2 * PHIP_MAX_MVEC);
@@ -78,7 +78,7 @@ extern "C" int phip_finalize(phip_ctx c)
   PHIP_CHECK_HIP(hipSetDevice(c->device));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->comm_stream));
-  hipFree(c->d_ticket); hipHostFree(c->h_ll); hipFree(c->d_ring); hipHostFree(c->h_ring);
+  hipHostFree(c->h_ll); hipFree(c->d_ring); hipHostFree(c->h_ring);
   hipFree(c->d_partials); hipFree(c->d_result); hipHostFree(c->h_result); hipFree(c->d_flag); hipHostFree(c->h_flag);
   if (c->prof) {
     for (int k = 0; k < 2; k++) for (int w = 0; w < 2; w++) for (hipEvent_t e : c->prof->ev[k][w]) hipEventDestroy(e);
@@ -306,7 +306,7 @@ int phip_ticket_open(phip_ctx c, int nvals, int publish, phip_ticket *t, RedCtl 
   const unsigned long long seq = phip_next_seq(&c->ring_seq);
   const int                slot = (int)(seq % PHIP_RING);
   t->slot = slot; t->nvals = nvals; t->seq = seq;
-  ctl->partial = c->d_partials; ctl->ticket = c->d_ticket; ctl->d_out = c->d_ring + (size_t)slot * PHIP_RING_VALS;
+  ctl->partial = c->d_partials; ctl->pflag = phip_next_pflag(c); ctl->d_out = c->d_ring + (size_t)slot * PHIP_RING_VALS;
   ctl->kofs = 0; ctl->accumulate = 0; ctl->npub = 0; ctl->h_ll = NULL; ctl->seq = 0;
   if (publish) { ctl->h_ll = c->h_ring_dev[slot].ll; ctl->seq = seq; ctl->npub = nvals; }
   return 0;
@@ -320,7 +320,7 @@ static int ticket_live(phip_ctx c, const phip_ticket *t)
 int phip_ticket_accumulate(phip_ctx c, const phip_ticket *t, int publish, RedCtl *ctl)
 {
   PHIP_REQUIRE(ticket_live(c, t), PHIP_ERR_ARG_WRONGSTATE, "phip_ticket_accumulate: the ticket has expired");
-  ctl->partial = c->d_partials; ctl->ticket = c->d_ticket; ctl->d_out = c->d_ring + (size_t)t->slot * PHIP_RING_VALS;
+  ctl->partial = c->d_partials; ctl->pflag = phip_next_pflag(c); ctl->d_out = c->d_ring + (size_t)t->slot * PHIP_RING_VALS;
   ctl->kofs = 0; ctl->accumulate = 1; ctl->npub = 0; ctl->h_ll = NULL; ctl->seq = 0;
   if (publish) { ctl->h_ll = c->h_ring_dev[t->slot].ll; ctl->seq = t->seq; ctl->npub = t->nvals; }
   return 0;

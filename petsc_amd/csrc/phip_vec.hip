@@ -4,7 +4,7 @@
 // Algorithmic bytes: dot 16n, norm 8n, axpy/aypx/pointwise 24n, waxpy 24n, scale 16n, copy 16n, set 8n,
 // mdot(nv) 8n(nv+1), maxpy(nv) 8n(nv+2).
 // Reductions: fixed grid of at most PHIP_RED_GRID workgroups; wavefront (64-lane) shuffle reduction -> LDS across the 4 waves ->
-// one partial per workgroup, stored write-through (sc1); the workgroup whose arrival ticket is last sums the partials in a
+// one partial per workgroup, stored write-through (sc1) as flagged words; the workgroup with the highest index collects them in a
 // fixed order (deterministic for a given n, whichever workgroup that is), writes the result to device memory and, for the calls
 // that return a host scalar, into a pinned slot followed by a sequence word the host spins on: one launch per reduction,
 // no second kernel, no copy, no stream synchronisation.  Hand-off form: MI355X_MICROARCH.md "Hand-offs measured with sc1 loads"
@@ -369,7 +369,7 @@ static int reduce_launch(phip_ctx c, int kind, int32_t n, const double *d_x, int
   /* pub: publish into that slot / sequence word (a by-product ticket) instead of the context's blocking-call slot */
   const int grid = reduce_grid(n);
   RedCtl    ctl;
-  ctl.partial = c->d_partials; ctl.ticket = c->d_ticket; ctl.d_out = d_out; ctl.h_ll = NULL; ctl.seq = 0; ctl.npub = 0; ctl.kofs = 0; ctl.accumulate = 0;
+  ctl.partial = c->d_partials; ctl.pflag = 0; ctl.d_out = d_out; ctl.h_ll = NULL; ctl.seq = 0; ctl.npub = 0; ctl.kofs = 0; ctl.accumulate = 0;
   if (kind == 0) {
     PHIP_REQUIRE(nv >= 0 && nv <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_reduce_local: nv=%d (max %d)", nv, PHIP_MAX_MVEC);
     PHIP_REQUIRE(h_dy || !nv, PHIP_ERR_ARG_NULL, "phip_vec_reduce_local: null vector list");
@@ -380,6 +380,7 @@ static int reduce_launch(phip_ctx c, int kind, int32_t n, const double *d_x, int
       MVPack    P;
       for (int k = 0; k < MV_MAX; k++) { P.y[k] = (k < g) ? h_dy[k0 + k] : d_x; P.a[k] = 0.0; }
       ctl.kofs = k0;
+      ctl.pflag = phip_next_pflag(c); /* every launch marks its partials with a flag of its own */
       if (publish && k0 + g == nv) {
         if (pub) { ctl.h_ll = pub->h_ll; ctl.seq = pub->seq; ctl.npub = nv; }
         else { ctl.h_ll = c->h_ll_dev; ctl.seq = phip_next_seq(&c->seq); ctl.npub = nv; *seq_out = ctl.seq; }
@@ -400,6 +401,7 @@ static int reduce_launch(phip_ctx c, int kind, int32_t n, const double *d_x, int
     if (pub) { ctl.h_ll = pub->h_ll; ctl.seq = pub->seq; ctl.npub = (kind == 4) ? 2 : 1; }
     else { ctl.h_ll = c->h_ll_dev; ctl.seq = phip_next_seq(&c->seq); ctl.npub = (kind == 4) ? 2 : 1; *seq_out = ctl.seq; }
   }
+  ctl.pflag = phip_next_pflag(c);
   switch (kind) {
   case 1: hipLaunchKernelGGL((norm_kernel<1>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, ctl); break;
   case 2: hipLaunchKernelGGL((norm_kernel<2>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, ctl); break;
