@@ -61,7 +61,7 @@ struct phip_mat_s {
   /* SELL-dict layout (stencil-like matrices) */
   int      fmt_user;   /* 0 auto, 1 CSR row blocks, 2 SELL-dict (error if not eligible) */
   int      sell_on, sell_built;
-  int32_t  sell_nslices, sell_noffs;
+  int32_t  sell_nslices, sell_noffs, sell_maxlen;
   int64_t  sell_padded;
   double  *d_sval;
   uint8_t *d_scode, *d_slen;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(int32_t nbl
    STAGE: the x entries a slice needs form a few contiguous segments (one per cluster of nearby diagonals: 9 for a 27-point stencil);
    the workgroup copies them into LDS with coalesced loads and gathers from there, so each x entry crosses L2 once per cluster
    instead of once per diagonal and the per-lane gathers no longer thrash L1. */
-template <bool NT, bool DOT, bool STAGE>
+template <bool NT, bool DOT, bool STAGE, int U>
 __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int32_t n, int32_t nslices, const int64_t *__restrict__ sptr, const uint8_t *__restrict__ slen,
                                                                  const double *__restrict__ sval, const uint8_t *__restrict__ scode,
                                                                  const int32_t *__restrict__ soffs, int noffs, const int32_t *__restrict__ scl, int ncl,
@@ -276,20 +276,20 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
     if (DOT && act) { dv0 = dotv[r0]; if (has1) dv1 = dotv[r0 + 1]; }
     double s0 = y0, s1 = y1;
     int    s = 0;
-    for (; s + 4 <= lm; s += 4) {
-      double2 v[4];
-      uchar2  c[4];
+    for (; s + U <= lm; s += U) {
+      double2 v[U];
+      uchar2  c[U];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { v[u] = ld_stream<NT>(vp + (size_t)(s + u) * (SELL_H / 2)); c[u] = ld_stream<NT>(cp + (size_t)(s + u) * (SELL_H / 2)); }
-      double xa[4], xb[4];
+      for (int u = 0; u < U; u++) { v[u] = ld_stream<NT>(vp + (size_t)(s + u) * (SELL_H / 2)); c[u] = ld_stream<NT>(cp + (size_t)(s + u) * (SELL_H / 2)); }
+      double xa[U], xb[U];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < U; u++) {
         const bool a0 = s + u < l0, a1 = s + u < l1;
         xa[u] = xv[a0 ? g0 + offs[c[u].x] : 0];
         xb[u] = xv[a1 ? g0 + 1 + offs[c[u].y] : 0];
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < U; u++) {
         if (s + u < l0) s0 = s0 + v[u].x * xa[u];
         if (s + u < l1) s1 = s1 + v[u].y * xb[u];
       }
@@ -462,6 +462,8 @@ static int setup_sell(phip_mat A, const int32_t *h_j, const double *h_a)
   A->sell_nslices = (A->m + SELL_H - 1) / SELL_H;
   A->sell_noffs = (int32_t)soffs.size();
   A->sell_padded = (*A->h_sptr)[(size_t)A->sell_nslices];
+  A->sell_maxlen = 0;
+  for (int32_t r = 0; r < A->R; r++) { const int32_t L = (*A->h_rowptr)[(size_t)r + 1] - (*A->h_rowptr)[(size_t)r]; if (L > A->sell_maxlen) A->sell_maxlen = L; }
   A->sell_on = 1; A->sell_built = 1;
   /* x staging plan: sort the diagonals, cut into clusters no wider than SELL_CL_SPAN, one LDS segment of SELL_H + width per cluster */
   std::vector<int32_t> scl, sldsoff(SELL_MAX_OFFS, 0);
@@ -635,14 +637,20 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
        206 -> 220 us): the gathers are not what bounds this kernel.  Off unless PHIP_SELL_STAGE=1. */
     static const int stage_env = getenv("PHIP_SELL_STAGE") ? atoi(getenv("PHIP_SELL_STAGE")) : 0;
     const bool     stage = A->stage_ok && (stage_env != 0 || A->stage_user);
-#define SELL_LAUNCH(NTv, STv)                                                                                                                        \
-  hipLaunchKernelGGL((spmv_sell_kernel<NTv, DOT, STv>), dim3(grid), dim3(PHIP_THREADS), (STv) ? sizeof(double) * (size_t)A->stage_lds_doubles : 0, st, A->m, \
+#define SELL_LAUNCH2(NTv, STv, Uv)                                                                                                                        \
+  hipLaunchKernelGGL((spmv_sell_kernel<NTv, DOT, STv, Uv>), dim3(grid), dim3(PHIP_THREADS), (STv) ? sizeof(double) * (size_t)A->stage_lds_doubles : 0, st, A->m, \
                      A->n, A->sell_nslices, A->d_sptr, A->d_slen, A->d_sval, A->d_scode, (STv) ? A->d_sldsoff : A->d_soffs, A->sell_noffs, A->d_scl,      \
                      A->stage_ncl, d_x, d_yin, d_yout, add, d_v, ctl)
+    /* slots requested per lane before the gathers start: 8 for long rows (27-point 192^3: 361.9 -> 349.7 us), 4 otherwise (rows of 7
+       never fill a batch of 8: 27.1 -> 36.1 us); PHIP_SELL_UNROLL=4|8 overrides */
+    static const int unroll_env = getenv("PHIP_SELL_UNROLL") ? atoi(getenv("PHIP_SELL_UNROLL")) : 0;
+    const int        unroll = unroll_env ? unroll_env : (A->sell_maxlen >= 16 ? 8 : 4);
+#define SELL_LAUNCH(NTv, STv) do { if (unroll == 8) SELL_LAUNCH2(NTv, STv, 8); else SELL_LAUNCH2(NTv, STv, 4); } while (0)
     if (nt && stage) SELL_LAUNCH(true, true);
     else if (nt) SELL_LAUNCH(true, false);
     else if (stage) SELL_LAUNCH(false, true);
     else SELL_LAUNCH(false, false);
+#undef SELL_LAUNCH2
 #undef SELL_LAUNCH
   } else {
     static const int dot_grid_env = getenv("PHIP_SPMV_DOT_GRID") ? atoi(getenv("PHIP_SPMV_DOT_GRID")) : 0;
