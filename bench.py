@@ -87,9 +87,13 @@ def main():
     kind, n = parse_workload(a.workload)
 
     if world > 1:
-        ids = [P.Comm.unique_id() if rank == 0 else None]
+        # data path: RCCL (one GPU per rank).  PHIP_BENCH_BACKEND=shm stages the ghost exchange through host shared memory instead, so
+        # that the ranks may share a GPU: a rehearsal of this script's distributed flow on a one-GPU box, not a measurement.
+        backend = os.environ.get("PHIP_BENCH_BACKEND", "rccl")
+        ids = [(P.Comm.unique_id() if backend == "rccl" else os.urandom(128)) if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        comm = P.Comm(device=local_rank, backend="rccl", id128=ids[0], nranks=world, rank=rank)
+        ndev = max(torch.cuda.device_count(), 1)
+        comm = P.Comm(device=local_rank % ndev, backend=backend, id128=ids[0], nranks=world, rank=rank)
     else:
         comm = P.Comm(device=0, backend="self")
     L = capi.load()

@@ -205,8 +205,9 @@ int phip_comm_allreduce(phip_comm comm, double *d_buf, int32_t n, int op);
  * propagates), n <= PHIP_MAX_MVEC, combined in rank order on every rank (identical bits everywhere).  Ranks of one node ("rccl",
  * "shm", "threads" backends) meet in a shared-memory ring -- no kernel, no RCCL call, about a microsecond; ranks on several nodes
  * fall back to ncclAllReduce through a device staging buffer; the callbacks backend uses the application's all-gather.
- * backend "shm" (phip_comm_create): processes of one node joined by that ring alone (id128 = any 128-byte key the ranks share);
- * it offers this call, phip_comm_allgather_host and phip_comm_barrier, and carries no device traffic. */
+ * backend "shm" (phip_comm_create): processes of one node joined by that ring alone (id128 = any 128-byte key the ranks share).
+ * Its host collectives run through the ring; its ghost exchanges are staged through the host (functional, slow): several processes may
+ * share ONE GPU with it, which RCCL refuses, so the multi-process path can be rehearsed on a one-GPU box.  No phip_comm_allreduce. */
 int phip_comm_allreduce_host(phip_comm comm, double *h_vals, int32_t n, int op);
 /* host-side collectives used at set-up (the PetscGatherNumberOfMessages/MessageLengths + Isend/Irecv handshake of
  * VecScatterCreate_PtoS, vpscat.c:2346-2392): all-gather of fixed-size records and variable all-to-all of int32 lists */

@@ -9,7 +9,9 @@
 //                   result to pinned host memory, and the ranks of a node combine them through a shared-memory ring
 //                   (phip_comm_allreduce_host below): a few hundred nanoseconds per rank instead of a collective kernel launch.
 // backend "shm"     the host side of "rccl" alone: ranks are processes of one node joined by the shared-memory ring (host all-reduce,
-//                   all-gather, barrier); no device traffic.  Used by the CPU tests of that ring.
+//                   all-gather, all-to-all, barrier).  Ghost exchanges are staged through the host and that ring: functional, so that
+//                   several processes can share ONE GPU (RCCL refuses that) and the whole multi-process path -- bench.py under
+//                   torch.distributed.run included -- can be rehearsed on a one-GPU box; not a performance path.
 // backend "self"    size 1.
 // backend "threads" the ranks are host threads of one process that share one GPU; collectives rendezvous through a
 //                   process-wide table.  It exists so that the distributed code path (plan handshake, pack kernel, lvec
@@ -156,6 +158,7 @@ struct phip_halo_s {
   int32_t   ntgt;
   int32_t  *d_tgt, *d_tptr, *d_tpos;
   const double *rev_lvec;
+  std::vector<int32_t> cnt; /* shm backend: cnt[p*size+q] = entries rank p sends to rank q in the forward exchange */
 };
 
 /* ---- host reduction ring: attach / detach / one round -------------------------------------------------------------------- */
@@ -517,6 +520,23 @@ extern "C" int phip_comm_allgather_host(phip_comm c, const void *h_send, void *h
   return 0;
 }
 
+/* shm backend: all-gather of buffers of different lengths (lengths first, then the data padded to the longest) */
+static int shm_allgatherv(phip_comm c, const void *mine, size_t my_bytes, std::vector<std::vector<unsigned char>> &all)
+{
+  std::vector<uint64_t> len((size_t)c->size);
+  uint64_t              me = my_bytes;
+  int                   rc = phip_comm_allgather_host(c, &me, len.data(), sizeof(uint64_t));
+  if (rc) return rc;
+  size_t mx = 8;
+  for (int p = 0; p < c->size; p++) if (len[(size_t)p] > mx) mx = (size_t)len[(size_t)p];
+  std::vector<unsigned char> send(mx, 0), recv(mx * (size_t)c->size);
+  if (my_bytes) memcpy(send.data(), mine, my_bytes);
+  if ((rc = phip_comm_allgather_host(c, send.data(), recv.data(), mx))) return rc;
+  all.assign((size_t)c->size, std::vector<unsigned char>());
+  for (int p = 0; p < c->size; p++) all[(size_t)p].assign(recv.begin() + (long)(mx * (size_t)p), recv.begin() + (long)(mx * (size_t)p + (size_t)len[(size_t)p]));
+  return 0;
+}
+
 extern "C" int phip_comm_alltoallv_i32(phip_comm c, const int32_t *h_send, const int32_t *send_counts, int32_t *h_recv, const int32_t *recv_counts)
 {
   PHIP_REQUIRE(c && send_counts && recv_counts, PHIP_ERR_ARG_NULL, "phip_comm_alltoallv_i32: null argument");
@@ -527,7 +547,21 @@ extern "C" int phip_comm_alltoallv_i32(phip_comm c, const int32_t *h_send, const
     if (send_counts[0]) memcpy(h_recv, h_send, sizeof(int32_t) * (size_t)send_counts[0]);
     return 0;
   }
-  PHIP_REQUIRE(c->backend != BACKEND_SHM, PHIP_ERR_SUP, "phip_comm_alltoallv_i32: not offered by the shm backend");
+  if (c->backend == BACKEND_SHM) { /* everyone gathers every rank's counts and lists, and keeps its own share */
+    std::vector<int32_t> sc((size_t)c->size * (size_t)c->size);
+    int rc = phip_comm_allgather_host(c, send_counts, sc.data(), sizeof(int32_t) * (size_t)c->size);
+    if (rc) return rc;
+    std::vector<std::vector<unsigned char>> all;
+    if ((rc = shm_allgatherv(c, h_send, sizeof(int32_t) * so[(size_t)c->size], all))) return rc;
+    for (int p = 0; p < c->size; p++) {
+      size_t off = 0;
+      for (int q = 0; q < c->rank; q++) off += (size_t)sc[(size_t)p * (size_t)c->size + (size_t)q];
+      const int32_t cnt = sc[(size_t)p * (size_t)c->size + (size_t)c->rank];
+      PHIP_REQUIRE(cnt == recv_counts[p], PHIP_ERR_ARG_SIZ, "phip_comm_alltoallv_i32: rank %d sends %d to %d, which expects %d", p, cnt, c->rank, recv_counts[p]);
+      if (cnt) memcpy(h_recv + ro[(size_t)p], all[(size_t)p].data() + sizeof(int32_t) * off, sizeof(int32_t) * (size_t)cnt);
+    }
+    return 0;
+  }
   if (c->backend == BACKEND_CALLBACKS) {
     int rc = c->cb_alltoallv(c->cb_user, h_send, send_counts, h_recv, recv_counts);
     PHIP_REQUIRE(rc == 0, PHIP_ERR_LIB, "phip_comm_alltoallv_i32: the application's all-to-all callback failed with %d", rc);
@@ -620,6 +654,13 @@ extern "C" int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_
     PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream)); /* the staging vectors go out of scope here */
   }
   PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (comm->backend == BACKEND_SHM && comm->size > 1) { /* who sends how much to whom: the staged exchange finds its segments with it */
+    std::vector<int32_t> row((size_t)comm->size, 0);
+    for (int i = 0; i < to_n; i++) row[(size_t)to_procs[i]] = to_starts[i + 1] - to_starts[i];
+    h->cnt.assign((size_t)comm->size * (size_t)comm->size, 0);
+    int rc = phip_comm_allgather_host(comm, row.data(), h->cnt.data(), sizeof(int32_t) * (size_t)comm->size);
+    if (rc) return rc;
+  }
   PHIP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
   PHIP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
   *out = h;
@@ -639,6 +680,35 @@ extern "C" int phip_halo_destroy(phip_halo h)
   return 0;
 }
 
+/* shm backend: one exchange staged through the host.  forward: every rank contributes its packed send buffer and picks, from each
+   neighbour's, the segment meant for it (into lvec).  reverse: every rank contributes its lvec and picks, from each neighbour's, the
+   segment of entries it owns (into the send buffer, which halo_unpack_add_kernel then adds into y). */
+static int shm_exchange(phip_halo h, int reverse, const double *d_src, size_t nsrc, double *d_dst)
+{
+  phip_comm c = h->comm;
+  phip_ctx  ctx = c->ctx;
+  const size_t P = (size_t)c->size, me = (size_t)c->rank;
+  std::vector<double> mine(nsrc + 1);
+  if (nsrc) PHIP_CHECK_HIP(hipMemcpyAsync(mine.data(), d_src, sizeof(double) * nsrc, hipMemcpyDeviceToHost, ctx->stream));
+  PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<std::vector<unsigned char>> all;
+  int rc = shm_allgatherv(c, mine.data(), sizeof(double) * nsrc, all);
+  if (rc) return rc;
+  const int                   npeer = reverse ? h->to_n : h->from_n;
+  const std::vector<int32_t> &procs = reverse ? h->to_procs : h->from_procs, &starts = reverse ? h->to_starts : h->from_starts;
+  for (int i = 0; i < npeer; i++) {
+    const size_t  p = (size_t)procs[(size_t)i];
+    const int32_t cnt = starts[(size_t)i + 1] - starts[(size_t)i];
+    size_t        off = 0; /* forward: what p sends to the ranks before me; reverse: what p received from the ranks before me */
+    for (size_t q = 0; q < me; q++) off += (size_t)(reverse ? h->cnt[q * P + p] : h->cnt[p * P + q]);
+    const int32_t have = reverse ? h->cnt[me * P + p] : h->cnt[p * P + me];
+    PHIP_REQUIRE(have == cnt && sizeof(double) * (off + (size_t)cnt) <= all[p].size(), PHIP_ERR_ARG_SIZ, "halo exchange: rank %d expects %d entries from rank %d, which holds %d for it", c->rank, cnt, (int)p, have);
+    if (cnt) PHIP_CHECK_HIP(hipMemcpyAsync(d_dst + starts[(size_t)i], all[p].data() + sizeof(double) * off, sizeof(double) * (size_t)cnt, hipMemcpyHostToDevice, ctx->stream));
+  }
+  PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream)); /* the staging buffers go out of scope */
+  return 0;
+}
+
 extern "C" int phip_halo_begin(phip_halo h, const double *d_x_local, double *d_lvec)
 {
   PHIP_REQUIRE(h && (d_x_local || !h->nsend) && (d_lvec || !h->nrecv), PHIP_ERR_ARG_NULL, "phip_halo_begin: null argument");
@@ -647,7 +717,7 @@ extern "C" int phip_halo_begin(phip_halo h, const double *d_x_local, double *d_l
   h->lvec = d_lvec;
   if (c->size == 1) return 0;
   PHIP_NEED_DEVICE(ctx, "phip_halo_begin");
-  PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS && c->backend != BACKEND_SHM, PHIP_ERR_SUP, "phip_halo_begin: this backend carries no device traffic");
+  PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS, PHIP_ERR_SUP, "phip_halo_begin: the callbacks backend carries set-up traffic only");
   if (h->nsend) {
     hipLaunchKernelGGL(halo_pack_kernel, dim3(phip_grid_for(h->nsend, 1, 1024)), dim3(PHIP_THREADS), 0, ctx->stream, h->nsend, h->d_to_indices, d_x_local, h->d_sendbuf);
     PHIP_CHECK_HIP(hipGetLastError());
@@ -672,6 +742,7 @@ extern "C" int phip_halo_begin(phip_halo h, const double *d_x_local, double *d_l
     PHIP_CHECK_HIP(hipEventRecord(h->ev_done, ctx->comm_stream));
     return 0;
   }
+  if (c->backend == BACKEND_SHM) return shm_exchange(h, 0, h->d_sendbuf, (size_t)h->nsend, d_lvec);
   /* threads: publish the packed buffer; the copies happen in phip_halo_end */
   PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   c->tg->slot_a[(size_t)c->rank] = h;
@@ -688,6 +759,7 @@ extern "C" int phip_halo_end(phip_halo h)
     PHIP_CHECK_HIP(hipStreamWaitEvent(ctx->stream, h->ev_done, 0));
     return 0;
   }
+  if (c->backend == BACKEND_SHM) return 0; /* done in phip_halo_begin */
   ThreadGroup *g = c->tg;
   g->barrier();
   for (int i = 0; i < h->from_n; i++) {
@@ -728,7 +800,7 @@ extern "C" int phip_halo_reverse_begin(phip_halo h, const double *d_lvec)
   h->rev_lvec = d_lvec;
   if (c->size == 1) return 0;
   PHIP_NEED_DEVICE(ctx, "phip_halo_reverse_begin");
-  PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS && c->backend != BACKEND_SHM, PHIP_ERR_SUP, "phip_halo_reverse_begin: this backend carries no device traffic");
+  PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS, PHIP_ERR_SUP, "phip_halo_reverse_begin: the callbacks backend carries set-up traffic only");
   if (c->backend == BACKEND_RCCL) {
     /* lvec is complete once everything queued on the compute stream so far has run; the receive buffer is the forward send buffer
        (one scatter context carries one exchange at a time, vscat.c:1670) */
@@ -749,6 +821,7 @@ extern "C" int phip_halo_reverse_begin(phip_halo h, const double *d_lvec)
     PHIP_CHECK_HIP(hipEventRecord(h->ev_done, ctx->comm_stream));
     return 0;
   }
+  if (c->backend == BACKEND_SHM) return shm_exchange(h, 1, d_lvec, (size_t)h->nrecv, h->d_sendbuf);
   /* threads: lvec must be complete before a peer copies from it in phip_halo_reverse_end */
   PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   c->tg->slot_a[(size_t)c->rank] = h;
@@ -762,7 +835,7 @@ extern "C" int phip_halo_reverse_end(phip_halo h, double *d_y)
   phip_ctx  ctx = c->ctx;
   if (c->size == 1) return 0;
   if (c->backend == BACKEND_RCCL) PHIP_CHECK_HIP(hipStreamWaitEvent(ctx->stream, h->ev_done, 0));
-  else {
+  else if (c->backend == BACKEND_THREADS) {
     ThreadGroup *g = c->tg;
     g->barrier();
     for (int i = 0; i < h->to_n; i++) {

@@ -22,8 +22,12 @@ def main():
     from petsc_amd import petsc as P, torchcomm
     from oracle.oracle import Oracle
     orc = Oracle()
-    ag, av = torchcomm.make_callbacks(dist)
-    comm = P.Comm.from_callbacks(-1, world, rank, ag, av)
+    if os.environ.get("PHIP_TEST_COMM") == "shm":
+        # the library's own multi-process communicator (shared-memory ring): all-gather and all-to-all of the plan handshake through it
+        comm = P.Comm(device=-1, backend="shm", id128=bytes.fromhex(os.environ["PHIP_TEST_KEY"]), nranks=world, rank=rank)
+    else:
+        ag, av = torchcomm.make_callbacks(dist)
+        comm = P.Comm.from_callbacks(-1, world, rank, ag, av)
     g = np.load(os.path.join(ROOT, "tests", "golden", "mat_%s.npz" % name), allow_pickle=False)
     ai, aj, aa, N = g["i"], g["j"], g["a"], int(g["N"])
     rg = orc.ownership_ranges(N, world)

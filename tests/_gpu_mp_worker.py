@@ -1,0 +1,61 @@
+"""Worker of tests/test_host_gpu.py::test_multiprocess_shared_gpu: one PROCESS per rank, all on GPU 0, joined by the "shm" backend
+(shared-memory ring for the host collectives, ghost exchange staged through the host).  argv: key(hex) nranks rank"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    key, n, r = bytes.fromhex(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    from petsc_amd import generators as G, petsc as P
+    from oracle.oracle import Oracle
+    orc = Oracle()
+    comm = P.Comm(device=0, backend="shm", id128=key, nranks=n, rank=r)
+    ai, aj, aa = G.convdiff3d_7pt(12, 10, 9)
+    N = len(ai) - 1
+    op = orc.operator(ai, aj, aa, n)
+    rg = orc.ownership_ranges(N, n)
+    rs, re = int(rg[r]), int(rg[r + 1])
+    xg = np.cos(np.arange(N) * 0.37)
+    A = P.Mat.from_global_csr(comm, ai, aj, aa)
+    x = P.Vec.from_array(comm, xg[rs:re], N)
+    y = x.duplicate()
+    A.mult(x, y)
+    yref = op.mult(xg)
+    assert np.abs(y.array() - yref[rs:re]).max() <= 1e-12 * np.abs(yref).max()
+    A.mult_transpose(x, y)
+    tref = op.mult_transpose(xg)
+    assert np.abs(y.array() - tref[rs:re]).max() <= 1e-12 * np.abs(tref).max()
+    assert abs(x.dot(x) - xg @ xg) <= 1e-12 * (xg @ xg) and x.norm(P.NORM_INFINITY) == np.abs(xg).max()
+    b_g = op.mult(np.ones(N))
+    b = P.Vec.from_array(comm, b_g[rs:re], N)
+    for ksp_type in ("gmres", "cg"):
+        if ksp_type == "cg":
+            sym = G.laplace3d_7pt(11, dirichlet_rows=False)
+            for o in (A, x, y, b):
+                o.destroy()
+            N = len(sym[0]) - 1
+            op = orc.operator(*sym, n)
+            rg = orc.ownership_ranges(N, n)
+            rs, re = int(rg[r]), int(rg[r + 1])
+            A = P.Mat.from_global_csr(comm, *sym)
+            b_g = op.mult(np.ones(N))
+            b = P.Vec.from_array(comm, b_g[rs:re], N)
+        sol = b.duplicate()
+        ksp = P.KSP(comm, ksp_type, "jacobi")
+        ksp.set_operators(A)
+        ksp.set_tolerances(rtol=1e-9)
+        res = ksp.solve(b, sol)
+        ref = op.solve(b_g, ksp_type, "jacobi", rtol=1e-9)
+        assert abs(res["its"] - ref["its"]) <= 1 and res["reason"] == ref["reason"], (res, ref["its"])
+        assert np.abs(sol.array() - ref["x"][rs:re]).max() <= 1e-8
+        ksp.destroy(); sol.destroy()
+    comm.finalize()
+    print("mp ok rank %d" % r)
+
+
+if __name__ == "__main__":
+    main()

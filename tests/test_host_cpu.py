@@ -163,11 +163,13 @@ def _free_port():
     return p
 
 
-def _run_world(world, name, mode):
+def _run_world(world, name, mode, comm="callbacks"):
     port = _free_port()
     procs = []
+    key = os.urandom(128).hex()
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
+                   PHIP_TEST_COMM=comm, PHIP_TEST_KEY=key, PHIP_HOST_RING_TIMEOUT="60")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), name, mode], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
@@ -187,3 +189,10 @@ def _run_world(world, name, mode):
                                              (3, "medium", "arrays"), (3, "spd-real-int32-float64", "stash"), (4, "small", "local")])
 def test_mpiaij_plan_gloo(world, name, mode):
     _run_world(world, name, mode)
+
+
+@pytest.mark.parametrize("world,name,mode", [(2, "medium", "arrays"), (3, "small", "stash"), (4, "arco1", "local")])
+def test_mpiaij_plan_shm(world, name, mode):
+    """The same index work with the library's own multi-process communicator (backend "shm": shared-memory ring) carrying the
+    handshake -- the host side of what bench.py runs with under torch.distributed.run."""
+    _run_world(world, name, mode, comm="shm")

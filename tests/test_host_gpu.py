@@ -755,3 +755,27 @@ def test_byproduct_cache(orc, size):
     for key, val in ref.items():
         for on in (True, False):
             assert abs(res[key, on] - val) <= 1e-12 * max(abs(val), 1.0), (key, on, res[key, on], val)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_multiprocess_shared_gpu(n):
+    """One process per rank (as under torch.distributed.run), all on GPU 0, joined by the "shm" backend: products, transposed products,
+    reductions through the cross-process shared-memory ring, GMRES and CG against the oracle."""
+    import subprocess
+    import sys
+    key = os.urandom(128).hex()
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PHIP_HOST_RING_TIMEOUT="60")
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "_gpu_mp_worker.py"), key, str(n), str(r)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(n)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=100)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            o, _ = p.communicate()
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "mp ok rank %d" % r in o, o[-3000:]
