@@ -22,3 +22,21 @@ def test_mirror_under_sanitizers(tmp_path):
     assert b.returncode == 0, b.stderr[-3000:]
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0 and "asan driver ok" in r.stdout, (r.stdout + r.stderr)[-4000:]
+
+
+def test_host_ring_under_tsan(tmp_path):
+    """The shared-memory reduction ring (phip_comm_allreduce_host) under ThreadSanitizer: four thread-ranks, 40 000 rounds."""
+    lib = str(tmp_path / "libpetschip_tsan.so")
+    srcs = [os.path.join(ROOT, "petsc_amd", "csrc", f) for f in ("phip_runtime.hip", "phip_spmv.hip", "phip_vec.hip", "phip_comm.hip")]
+    b = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-w", "-Xarch_host", "-fsanitize=thread",
+                        "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), *srcs, "-o", lib, "-ldl"], capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stderr[-3000:]
+    exe = str(tmp_path / "tsan_ring")
+    b = subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-g", "-O1", "-fsanitize=thread", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "native", "tsan_ring.cpp"), lib, "-Wl,-rpath," + str(tmp_path), "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", exe],
+                       capture_output=True, text=True, timeout=300)
+    if b.returncode != 0 and "tsan" in b.stderr:
+        pytest.skip("ThreadSanitizer runtime not available: " + b.stderr[-300:])
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "tsan ring ok" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr, (r.stdout + r.stderr)[-4000:]
