@@ -413,6 +413,7 @@ extern "C" int phip_comm_allreduce(phip_comm c, double *d_buf, int32_t n, int op
   PHIP_REQUIRE(op == 0 || op == 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_allreduce: op %d", op);
   if (c->size == 1 || n == 0) return 0;
   PHIP_NEED_DEVICE(c->ctx, "phip_comm_allreduce");
+  PHIP_FLUSH(c->ctx);
   PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS && c->backend != BACKEND_SHM, PHIP_ERR_SUP, "phip_comm_allreduce: this backend carries no device traffic");
   if (c->backend == BACKEND_RCCL) {
     PHIP_CHECK_NCCL(g_rccl.AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->nccl, c->ctx->stream));
@@ -460,6 +461,7 @@ extern "C" int phip_comm_allreduce_host(phip_comm c, double *h_vals, int32_t n, 
     for (int p = 0; p < c->size; p++) peers[p] = (const unsigned char *)(gathered.data() + (size_t)p * (size_t)n);
   } else {
     PHIP_REQUIRE(c->backend == BACKEND_RCCL, PHIP_ERR_SUP, "phip_comm_allreduce_host: this communicator has no host ring");
+    PHIP_FLUSH(c->ctx);
     PHIP_CHECK_HIP(hipMemcpyAsync(c->d_stage, h_vals, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->ctx->stream));
     PHIP_CHECK_NCCL(g_rccl.AllReduce(c->d_stage, c->d_stage, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->nccl, c->ctx->stream));
     PHIP_CHECK_HIP(hipMemcpyAsync(h_vals, c->d_stage, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->ctx->stream));
@@ -717,6 +719,7 @@ extern "C" int phip_halo_begin(phip_halo h, const double *d_x_local, double *d_l
   h->lvec = d_lvec;
   if (c->size == 1) return 0;
   PHIP_NEED_DEVICE(ctx, "phip_halo_begin");
+  PHIP_FLUSH(ctx);
   PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS, PHIP_ERR_SUP, "phip_halo_begin: the callbacks backend carries set-up traffic only");
   if (h->nsend) {
     hipLaunchKernelGGL(halo_pack_kernel, dim3(phip_grid_for(h->nsend, 1, 1024)), dim3(PHIP_THREADS), 0, ctx->stream, h->nsend, h->d_to_indices, d_x_local, h->d_sendbuf);
@@ -755,6 +758,7 @@ extern "C" int phip_halo_end(phip_halo h)
   phip_comm c = h->comm;
   phip_ctx  ctx = c->ctx;
   if (c->size == 1) return 0;
+  PHIP_FLUSH(ctx);
   if (c->backend == BACKEND_RCCL) {
     PHIP_CHECK_HIP(hipStreamWaitEvent(ctx->stream, h->ev_done, 0));
     return 0;
@@ -800,6 +804,7 @@ extern "C" int phip_halo_reverse_begin(phip_halo h, const double *d_lvec)
   h->rev_lvec = d_lvec;
   if (c->size == 1) return 0;
   PHIP_NEED_DEVICE(ctx, "phip_halo_reverse_begin");
+  PHIP_FLUSH(ctx);
   PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS, PHIP_ERR_SUP, "phip_halo_reverse_begin: the callbacks backend carries set-up traffic only");
   if (c->backend == BACKEND_RCCL) {
     /* lvec is complete once everything queued on the compute stream so far has run; the receive buffer is the forward send buffer
@@ -834,6 +839,7 @@ extern "C" int phip_halo_reverse_end(phip_halo h, double *d_y)
   phip_comm c = h->comm;
   phip_ctx  ctx = c->ctx;
   if (c->size == 1) return 0;
+  PHIP_FLUSH(ctx);
   if (c->backend == BACKEND_RCCL) PHIP_CHECK_HIP(hipStreamWaitEvent(ctx->stream, h->ev_done, 0));
   else if (c->backend == BACKEND_THREADS) {
     ThreadGroup *g = c->tg;

@@ -35,6 +35,12 @@ struct phip_ctx_s {
   unsigned long long ring_seq; // tickets issued so far
   int         *d_flag;      // small int scratch (jacobi zero flag)
   int         *h_flag;      // pinned
+  /* elementwise operations wait here until something else needs the stream: up to PHIP_EW_BATCH of them leave in ONE launch
+     (phip_vec.hip, "batched elementwise operations") */
+  struct phip_ew_op { int op, hx, hy, hz; double *out; const double *x, *y, *z; double a, b, g; } ew[4];
+  int          ew_n;        // pending operations
+  int32_t      ew_len;      // their common vector length
+  int          ew_batching; // 0: every operation is launched at once (PHIP_EW_BATCH=0)
   int          prof_on;     // phip_profile_enable: hipEvent pair around every SpMV launch
   struct phip_prof_s *prof;
 };
@@ -53,6 +59,12 @@ int phip_ticket_open(phip_ctx c, int nvals, int publish, phip_ticket *t, struct 
 int phip_ticket_accumulate(phip_ctx c, const phip_ticket *t, int publish, struct RedCtl *ctl);
 
 int phip_prof_open(phip_ctx c, int kind, hipEvent_t *start, hipEvent_t *stop);
+
+/* launch the pending elementwise operations (phip_vec.hip).  Every entry point that queues other work on the stream, reads or frees
+   device memory, or waits for the stream calls this first. */
+#define PHIP_EW_BATCH 4
+int phip_ew_flush(phip_ctx c);
+#define PHIP_FLUSH(c) do { if ((c)->ew_n) { int _frc = phip_ew_flush(c); if (_frc) return _frc; } } while (0)
 
 void phip_set_error(const char *fmt, ...);
 

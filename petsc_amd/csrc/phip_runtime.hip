@@ -51,6 +51,7 @@ extern "C" int phip_init(int device, phip_ctx *out)
   PHIP_CHECK_HIP(hipMalloc((void **)&c->d_partials, sizeof(unsigned long long) * 2 * PHIP_MAX_MVEC * PHIP_RED_BLOCKS));
   PHIP_CHECK_HIP(hipMemsetAsync(c->d_partials, 0, sizeof(unsigned long long) * 2 * PHIP_MAX_MVEC * PHIP_RED_BLOCKS, c->stream));
   c->pseq = 0;
+  c->ew_n = 0; c->ew_batching = !(getenv("PHIP_EW_BATCH") && !atoi(getenv("PHIP_EW_BATCH")));
   PHIP_CHECK_HIP(hipMalloc((void **)&c->d_result, sizeof(double) * PHIP_MAX_MVEC));
   PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_result, sizeof(double) * PHIP_MAX_MVEC, hipHostMallocDefault));
   PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_ll, sizeof(unsigned long long) * 2 * PHIP_MAX_MVEC, hipHostMallocMapped | hipHostMallocCoherent));
@@ -76,6 +77,7 @@ extern "C" int phip_finalize(phip_ctx c)
   if (!c) return 0;
   if (c->device < 0) { free(c); return 0; }
   PHIP_CHECK_HIP(hipSetDevice(c->device));
+  PHIP_FLUSH(c);
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->comm_stream));
   hipHostFree(c->h_ll); hipFree(c->d_ring); hipHostFree(c->h_ring);
@@ -122,6 +124,7 @@ extern "C" int phip_malloc(phip_ctx c, size_t bytes, void **d_ptr)
 extern "C" int phip_free(phip_ctx c, void *d_ptr)
 {
   if (c && c->device < 0) return 0;
+  if (c) PHIP_FLUSH(c); /* a pending operation may still name this buffer */
   if (d_ptr) PHIP_CHECK_HIP(hipFree(d_ptr));
   return 0;
 }
@@ -130,6 +133,7 @@ extern "C" int phip_memcpy_h2d(phip_ctx c, void *d_dst, const void *h_src, size_
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_memcpy_h2d: null context");
   if (!bytes || c->device < 0) return 0;
+  PHIP_FLUSH(c);
   PHIP_CHECK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream)); /* pageable host source may be reused by the caller at once */
   return 0;
@@ -139,6 +143,7 @@ extern "C" int phip_memcpy_d2h(phip_ctx c, void *h_dst, const void *d_src, size_
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_memcpy_d2h: null context");
   PHIP_NEED_DEVICE(c, "phip_memcpy_d2h");
+  PHIP_FLUSH(c);
   if (bytes) PHIP_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   return 0;
@@ -148,6 +153,7 @@ extern "C" int phip_memcpy_d2d(phip_ctx c, void *d_dst, const void *d_src, size_
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_memcpy_d2d: null context");
   PHIP_NEED_DEVICE(c, "phip_memcpy_d2d");
+  PHIP_FLUSH(c);
   if (bytes && d_dst != d_src) PHIP_CHECK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
@@ -156,6 +162,7 @@ extern "C" int phip_sync(phip_ctx c)
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_sync: null context");
   if (c->device < 0) return 0;
+  PHIP_FLUSH(c);
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -164,12 +171,17 @@ extern "C" int phip_device_sync(phip_ctx c)
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_device_sync: null context");
   if (c->device < 0) return 0;
+  PHIP_FLUSH(c);
   PHIP_CHECK_HIP(hipSetDevice(c->device));
   PHIP_CHECK_HIP(hipDeviceSynchronize());
   return 0;
 }
 
-extern "C" void *phip_stream(phip_ctx c) { return c ? (void *)c->stream : NULL; }
+extern "C" void *phip_stream(phip_ctx c)
+{
+  if (c && c->ew_n) phip_ew_flush(c); /* the caller may queue work of its own behind ours */
+  return c ? (void *)c->stream : NULL;
+}
 
 /* copy n device scalars into the pinned slot as flagged words: one tiny kernel instead of a copy + stream sync */
 __global__ void publish_kernel(const double *__restrict__ src, int n, unsigned long long *ll, unsigned long long seq)
@@ -208,6 +220,7 @@ extern "C" int phip_read_scalars(phip_ctx c, const double *d_src, int32_t n, dou
   PHIP_REQUIRE(c && h_dst, PHIP_ERR_ARG_NULL, "phip_read_scalars: null argument");
   PHIP_REQUIRE(n >= 0 && n <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_read_scalars: n=%d", n);
   PHIP_NEED_DEVICE(c, "phip_read_scalars");
+  PHIP_FLUSH(c);
   if (!n) { PHIP_CHECK_HIP(hipStreamSynchronize(c->stream)); return 0; }
   const unsigned long long seq = phip_next_seq(&c->seq);
   hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(PHIP_MAX_MVEC), 0, c->stream, d_src, n, c->h_ll_dev, seq);
@@ -228,6 +241,7 @@ extern "C" int phip_event_create(phip_ctx c, void **event)
 extern "C" int phip_event_record(phip_ctx c, void *event)
 {
   PHIP_REQUIRE(c && event, PHIP_ERR_ARG_NULL, "phip_event_record: null argument");
+  PHIP_FLUSH(c);
   PHIP_CHECK_HIP(hipEventRecord((hipEvent_t)event, c->stream));
   return 0;
 }
@@ -279,6 +293,7 @@ extern "C" int phip_profile_read(phip_ctx c, int kind, int32_t *count, double *s
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_profile_read: null context");
   PHIP_REQUIRE(kind == 0 || kind == 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_profile_read: kind %d", kind);
   PHIP_NEED_DEVICE(c, "phip_profile_read");
+  PHIP_FLUSH(c);
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   double  s = 0.0, lo = 0.0, hi = 0.0;
   int32_t n = 0;
@@ -330,6 +345,7 @@ extern "C" int phip_ticket_values(phip_ctx c, const phip_ticket *t, double **d_v
 {
   PHIP_REQUIRE(c && d_vals, PHIP_ERR_ARG_NULL, "phip_ticket_values: null argument");
   PHIP_NEED_DEVICE(c, "phip_ticket_values");
+  PHIP_FLUSH(c);
   PHIP_REQUIRE(ticket_live(c, t), PHIP_ERR_ARG_WRONGSTATE, "phip_ticket_values: the ticket has expired");
   *d_vals = c->d_ring + (size_t)t->slot * PHIP_RING_VALS;
   return 0;

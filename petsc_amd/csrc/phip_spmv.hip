@@ -687,6 +687,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
 
 static int launch_spmv(phip_mat A, const double *d_x, const double *d_yin, double *d_yout, int add)
 {
+  PHIP_FLUSH(A->ctx);
   if (!A->nblocks) return 0;
   hipEvent_t e0 = NULL, e1 = NULL;
   if (A->ctx->prof_on) {
@@ -704,6 +705,7 @@ static int launch_spmv(phip_mat A, const double *d_x, const double *d_yin, doubl
 
 static int launch_spmv_dot(phip_mat A, const double *d_x, const double *d_yin, double *d_yout, int add, const double *d_v, const RedCtl &ctl)
 {
+  PHIP_FLUSH(A->ctx);
   hipEvent_t e0 = NULL, e1 = NULL;
   if (A->ctx->prof_on) {
     int rc = phip_prof_open(A->ctx, add ? 1 : 0, &e0, &e1);
@@ -720,6 +722,7 @@ extern "C" int phip_mat_mult(phip_mat A, const double *d_x, double *d_y)
 {
   PHIP_REQUIRE(A && (d_y || !A->m) && (d_x || !A->nnz), PHIP_ERR_ARG_NULL, "phip_mat_mult: null argument");
   PHIP_NEED_DEVICE(A->ctx, "phip_mat_mult");
+  PHIP_FLUSH(A->ctx);
   PHIP_REQUIRE(d_x != d_y || !A->m, PHIP_ERR_ARG_SIZ, "phip_mat_mult: x and y must be different vectors (matrix.c:2213)");
   if (A->use_cprow && A->m) PHIP_CHECK_HIP(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)A->m, A->ctx->stream)); /* aij.c:1296 */
   return launch_spmv(A, d_x, NULL, d_y, 0);
@@ -729,6 +732,7 @@ extern "C" int phip_mat_multadd(phip_mat A, const double *d_x, const double *d_y
 {
   PHIP_REQUIRE(A && ((d_y && d_z) || !A->m) && (d_x || !A->nnz), PHIP_ERR_ARG_NULL, "phip_mat_multadd: null argument");
   PHIP_NEED_DEVICE(A->ctx, "phip_mat_multadd");
+  PHIP_FLUSH(A->ctx);
   PHIP_REQUIRE(d_x != d_z || !A->m, PHIP_ERR_ARG_SIZ, "phip_mat_multadd: x and z must be different vectors (matrix.c:2361)");
   if (A->use_cprow && d_z != d_y && A->m)
     PHIP_CHECK_HIP(hipMemcpyAsync(d_z, d_y, sizeof(double) * (size_t)A->m, hipMemcpyDeviceToDevice, A->ctx->stream)); /* aij.c:1460-1462 */
@@ -739,6 +743,7 @@ extern "C" int phip_mat_mult_dot(phip_mat A, const double *d_x, double *d_y, con
 {
   PHIP_REQUIRE(A && t && (d_y || !A->m) && (d_v || !A->m) && (d_x || !A->nnz), PHIP_ERR_ARG_NULL, "phip_mat_mult_dot: null argument");
   PHIP_NEED_DEVICE(A->ctx, "phip_mat_mult_dot");
+  PHIP_FLUSH(A->ctx);
   PHIP_REQUIRE(d_x != d_y || !A->m, PHIP_ERR_ARG_SIZ, "phip_mat_mult_dot: x and y must be different vectors (matrix.c:2213)");
   if (A->use_cprow && A->m) PHIP_CHECK_HIP(hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)A->m, A->ctx->stream)); /* aij.c:1296 */
   RedCtl ctl;
@@ -751,6 +756,7 @@ extern "C" int phip_mat_multadd_dot(phip_mat A, const double *d_x, double *d_y, 
 {
   PHIP_REQUIRE(A && t && ((d_y && d_v) || !A->m) && (d_x || !A->nnz), PHIP_ERR_ARG_NULL, "phip_mat_multadd_dot: null argument");
   PHIP_NEED_DEVICE(A->ctx, "phip_mat_multadd_dot");
+  PHIP_FLUSH(A->ctx);
   PHIP_REQUIRE(d_x != d_y || !A->m, PHIP_ERR_ARG_SIZ, "phip_mat_multadd_dot: x and y must be different vectors");
   RedCtl ctl;
   int    rc = phip_ticket_accumulate(A->ctx, t, publish, &ctl);
@@ -811,6 +817,7 @@ extern "C" int phip_mat_getdiagonal(phip_mat A, double *d_v)
 {
   PHIP_REQUIRE(A && (d_v || !A->m), PHIP_ERR_ARG_NULL, "phip_mat_getdiagonal: null argument");
   PHIP_NEED_DEVICE(A->ctx, "phip_mat_getdiagonal");
+  PHIP_FLUSH(A->ctx);
   if (!A->m) return 0;
   PHIP_CHECK_HIP(hipMemsetAsync(d_v, 0, sizeof(double) * (size_t)A->m, A->ctx->stream)); /* VecSet(v,0) aij.c:1188 */
   if (A->R) {

@@ -218,17 +218,151 @@ __global__ __launch_bounds__(PHIP_THREADS) void pmult_reduce_kernel(int32_t n, d
   reduce_tail<3, 0>(acc, lds, ctl);
 }
 
+/* ---- batched elementwise operations -----------------------------------------------------------------
+   KSPSolve_CG issues VecAXPY(X,a,P); VecAXPY(R,-a,W); PCApply(R,Z) back to back (cg.c:222-225): three launches, and R is written by the
+   second and read again by the third.  Elementwise operations therefore wait in the context (phip_internal.h) until something else needs
+   the stream, and up to PHIP_EW_BATCH of them leave in one launch.  Every thread applies the operations IN CALL ORDER to the entries it
+   owns, so a later operation sees what an earlier one stored to the same entry (the operands of one entry never depend on another
+   entry), and what it stored is still in cache when the next operation asks for it.  Arithmetic per operation is that of the single
+   kernels (ew_apply), so results are bit-identical to unbatched execution.  RED: the last operation is w = x .* y with the by-product
+   sums of pmult_reduce_kernel. */
+struct EwBatch { int nops; phip_ctx_s::phip_ew_op op[PHIP_EW_BATCH]; };
+
+__device__ __forceinline__ double ew_apply_rt(int op, double a, double b, double g, double x, double y, double z)
+{
+  switch (op) {
+  case EW_AXPY: return ew_apply<EW_AXPY>(a, b, g, x, y, z);
+  case EW_AYPX: return ew_apply<EW_AYPX>(a, b, g, x, y, z);
+  case EW_XMY: return ew_apply<EW_XMY>(a, b, g, x, y, z);
+  case EW_WAXPY: return ew_apply<EW_WAXPY>(a, b, g, x, y, z);
+  case EW_WXPY: return ew_apply<EW_WXPY>(a, b, g, x, y, z);
+  case EW_WYMX: return ew_apply<EW_WYMX>(a, b, g, x, y, z);
+  case EW_AXPBY: return ew_apply<EW_AXPBY>(a, b, g, x, y, z);
+  case EW_SCALEX: return ew_apply<EW_SCALEX>(a, b, g, x, y, z);
+  case EW_AXPBYPCZ: return ew_apply<EW_AXPBYPCZ>(a, b, g, x, y, z);
+  case EW_PMULT: return ew_apply<EW_PMULT>(a, b, g, x, y, z);
+  case EW_PDIV: return ew_apply<EW_PDIV>(a, b, g, x, y, z);
+  case EW_SCALE: return ew_apply<EW_SCALE>(a, b, g, x, y, z);
+  case EW_SET: return ew_apply<EW_SET>(a, b, g, x, y, z);
+  default: return ew_apply<EW_RECIP>(a, b, g, x, y, z);
+  }
+}
+
+template <bool RED>
+__global__ __launch_bounds__(PHIP_THREADS) void ew_batch_kernel(int32_t n, EwBatch B, RedCtl ctl)
+{
+  __shared__ double lds[12];
+  double            acc[3] = {0.0, 0.0, 0.0};
+  const int64_t     n2 = n >> 1;
+  const int64_t     stride = (int64_t)gridDim.x * PHIP_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; i < n2; i += stride) {
+    for (int k = 0; k < B.nops; k++) {
+      const phip_ctx_s::phip_ew_op &o = B.op[k];
+      double2 xv = {0, 0}, yv = {0, 0}, zv = {0, 0}, r;
+      if (o.hx) xv = reinterpret_cast<const double2 *>(o.x)[i];
+      if (o.hy) yv = reinterpret_cast<const double2 *>(o.y)[i];
+      if (o.hz) zv = reinterpret_cast<const double2 *>(o.z)[i];
+      r.x = ew_apply_rt(o.op, o.a, o.b, o.g, xv.x, yv.x, zv.x);
+      r.y = ew_apply_rt(o.op, o.a, o.b, o.g, xv.y, yv.y, zv.y);
+      reinterpret_cast<double2 *>(o.out)[i] = r;
+      if (RED && k == B.nops - 1) {
+        acc[0] += r.x * r.x + r.y * r.y;
+        acc[1] += r.x * xv.x + r.y * xv.y;
+        acc[2] += r.x * yv.x + r.y * yv.y;
+      }
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int32_t i = n - 1;
+    for (int k = 0; k < B.nops; k++) {
+      const phip_ctx_s::phip_ew_op &o = B.op[k];
+      const double xv = o.hx ? o.x[i] : 0.0, yv = o.hy ? o.y[i] : 0.0, zv = o.hz ? o.z[i] : 0.0;
+      const double r = ew_apply_rt(o.op, o.a, o.b, o.g, xv, yv, zv);
+      o.out[i] = r;
+      if (RED && k == B.nops - 1) { acc[0] += r * r; acc[1] += r * xv; acc[2] += r * yv; }
+    }
+  }
+  if (RED) {
+    block_sum<3>(acc, lds);
+    __syncthreads();
+    reduce_tail<3, 0>(acc, lds, ctl);
+  }
+}
+
 /* ---- host launchers ---------------------------------------------------------------------------- */
 #define EW_GRID(n) phip_grid_for((n) / 2 + 1, 4, 2048)
-#define CHECK_CTX(c, name) do { PHIP_REQUIRE((c), PHIP_ERR_ARG_NULL, name ": null context"); PHIP_NEED_DEVICE((c), name); } while (0)
+#define CHECK_CTX_Q(c, name) do { PHIP_REQUIRE((c), PHIP_ERR_ARG_NULL, name ": null context"); PHIP_NEED_DEVICE((c), name); } while (0)
+/* every entry point except the queueing elementwise ones launches what is pending first */
+#define CHECK_CTX(c, name) do { CHECK_CTX_Q(c, name); PHIP_FLUSH(c); } while (0)
 #define CHECK_N(n, name) PHIP_REQUIRE((n) >= 0, PHIP_ERR_ARG_OUTOFRANGE, name ": negative length %d", (n))
+
+template <int OP, bool HX, bool HY, bool HZ>
+static int launch_ew_now(phip_ctx c, int32_t n, double *out, const double *x, const double *y, const double *z, double a, double b, double g)
+{
+  hipLaunchKernelGGL((ew_kernel<OP, HX, HY, HZ>), dim3(EW_GRID(n)), dim3(PHIP_THREADS), 0, c->stream, n, out, x, y, z, a, b, g);
+  PHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+/* one pending operation, launched by the kernel specialised for it */
+static int ew_launch_single(phip_ctx c, int32_t n, const phip_ctx_s::phip_ew_op &o)
+{
+  switch (o.op) {
+#define EW_CASE(OP, HX, HY, HZ) case OP: return launch_ew_now<OP, HX, HY, HZ>(c, n, o.out, o.x, o.y, o.z, o.a, o.b, o.g);
+    EW_CASE(EW_AXPY, true, true, false) EW_CASE(EW_AYPX, true, true, false) EW_CASE(EW_XMY, true, true, false) EW_CASE(EW_WAXPY, true, true, false)
+    EW_CASE(EW_WXPY, true, true, false) EW_CASE(EW_WYMX, true, true, false) EW_CASE(EW_AXPBY, true, true, false) EW_CASE(EW_SCALEX, true, false, false)
+    EW_CASE(EW_AXPBYPCZ, true, true, true) EW_CASE(EW_PMULT, true, true, false) EW_CASE(EW_PDIV, true, true, false) EW_CASE(EW_SCALE, true, false, false)
+    EW_CASE(EW_SET, false, false, false) EW_CASE(EW_RECIP, true, false, false)
+#undef EW_CASE
+  }
+  PHIP_REQUIRE(0, PHIP_ERR_LIB, "ew_launch_single: unknown operation %d", o.op);
+  return PHIP_ERR_LIB;
+}
+
+int phip_ew_flush(phip_ctx c)
+{
+  const int nops = c->ew_n;
+  c->ew_n = 0;
+  if (!nops) return 0;
+  if (nops == 1) return ew_launch_single(c, c->ew_len, c->ew[0]);
+  EwBatch B;
+  B.nops = nops;
+  for (int k = 0; k < nops; k++) B.op[k] = c->ew[k];
+  RedCtl none;
+  memset(&none, 0, sizeof(none));
+  hipLaunchKernelGGL((ew_batch_kernel<false>), dim3(EW_GRID(c->ew_len)), dim3(PHIP_THREADS), 0, c->stream, c->ew_len, B, none);
+  PHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+/* two operand arrays of length n may share a batch if they are the same array or do not overlap at all */
+static inline bool ew_compatible(const double *p, const double *q, int32_t n)
+{
+  if (!p || !q || p == q) return true;
+  return p + n <= q || q + n <= p;
+}
+static bool ew_can_join(phip_ctx c, int32_t n, const double *out, const double *x, const double *y, const double *z)
+{
+  if (!c->ew_batching || !c->ew_n) return c->ew_batching != 0;
+  if (c->ew_n >= PHIP_EW_BATCH || c->ew_len != n) return false;
+  const double *mine[4] = {out, x, y, z};
+  for (int k = 0; k < c->ew_n; k++) {
+    const double *theirs[4] = {c->ew[k].out, c->ew[k].hx ? c->ew[k].x : NULL, c->ew[k].hy ? c->ew[k].y : NULL, c->ew[k].hz ? c->ew[k].z : NULL};
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) if (!ew_compatible(mine[i], theirs[j], n)) return false;
+  }
+  return true;
+}
 
 template <int OP, bool HX, bool HY, bool HZ>
 static int launch_ew(phip_ctx c, int32_t n, double *out, const double *x, const double *y, const double *z, double a, double b, double g)
 {
   if (n == 0) return 0;
-  hipLaunchKernelGGL((ew_kernel<OP, HX, HY, HZ>), dim3(EW_GRID(n)), dim3(PHIP_THREADS), 0, c->stream, n, out, x, y, z, a, b, g);
-  PHIP_CHECK_HIP(hipGetLastError());
+  /* vectors whose double2 accesses would be misaligned, or batching switched off: at once, after whatever is pending */
+  if (!c->ew_batching) { PHIP_FLUSH(c); return launch_ew_now<OP, HX, HY, HZ>(c, n, out, x, y, z, a, b, g); }
+  if (!ew_can_join(c, n, out, HX ? x : NULL, HY ? y : NULL, HZ ? z : NULL)) PHIP_FLUSH(c);
+  phip_ctx_s::phip_ew_op &o = c->ew[c->ew_n++];
+  o.op = OP; o.hx = HX; o.hy = HY; o.hz = HZ; o.out = out; o.x = x; o.y = y; o.z = z; o.a = a; o.b = b; o.g = g;
+  c->ew_len = n;
   return 0;
 }
 
@@ -241,15 +375,15 @@ extern "C" int phip_vec_copy(phip_ctx c, int32_t n, const double *d_x, double *d
 
 extern "C" int phip_vec_set(phip_ctx c, int32_t n, double *d_x, double alpha)
 {
-  CHECK_CTX(c, "phip_vec_set"); CHECK_N(n, "phip_vec_set");
+  CHECK_CTX_Q(c, "phip_vec_set"); CHECK_N(n, "phip_vec_set");
   if (!n) return 0;
-  if (alpha == 0.0) { PHIP_CHECK_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * (size_t)n, c->stream)); return 0; } /* dvec2.c:559-560 */
+  if (alpha == 0.0) { PHIP_FLUSH(c); PHIP_CHECK_HIP(hipMemsetAsync(d_x, 0, sizeof(double) * (size_t)n, c->stream)); return 0; } /* dvec2.c:559-560 */
   return launch_ew<EW_SET, false, false, false>(c, n, d_x, NULL, NULL, NULL, alpha, 0, 0);
 }
 
 extern "C" int phip_vec_scale(phip_ctx c, int32_t n, double *d_x, double alpha)
 {
-  CHECK_CTX(c, "phip_vec_scale"); CHECK_N(n, "phip_vec_scale");
+  CHECK_CTX_Q(c, "phip_vec_scale"); CHECK_N(n, "phip_vec_scale");
   if (alpha == 0.0) return phip_vec_set(c, n, d_x, 0.0); /* bvec1.c:62-63 */
   if (alpha == 1.0) return 0;                             /* bvec1.c:64 */
   return launch_ew<EW_SCALE, true, false, false>(c, n, d_x, d_x, NULL, NULL, alpha, 0, 0);
@@ -257,14 +391,14 @@ extern "C" int phip_vec_scale(phip_ctx c, int32_t n, double *d_x, double alpha)
 
 extern "C" int phip_vec_axpy(phip_ctx c, int32_t n, double *d_y, double alpha, const double *d_x)
 {
-  CHECK_CTX(c, "phip_vec_axpy"); CHECK_N(n, "phip_vec_axpy");
+  CHECK_CTX_Q(c, "phip_vec_axpy"); CHECK_N(n, "phip_vec_axpy");
   if (alpha == 0.0) return 0; /* bvec1.c:86 */
   return launch_ew<EW_AXPY, true, true, false>(c, n, d_y, d_x, d_y, NULL, alpha, 0, 0);
 }
 
 extern "C" int phip_vec_aypx(phip_ctx c, int32_t n, double *d_y, double alpha, const double *d_x)
 {
-  CHECK_CTX(c, "phip_vec_aypx"); CHECK_N(n, "phip_vec_aypx");
+  CHECK_CTX_Q(c, "phip_vec_aypx"); CHECK_N(n, "phip_vec_aypx");
   if (alpha == 0.0) return phip_vec_copy(c, n, d_x, d_y);           /* dvec2.c:652-653 */
   if (alpha == 1.0) return phip_vec_axpy(c, n, d_y, alpha, d_x);    /* :654-655 */
   if (alpha == -1.0) return launch_ew<EW_XMY, true, true, false>(c, n, d_y, d_x, d_y, NULL, 0, 0, 0); /* :656-661 */
@@ -273,7 +407,7 @@ extern "C" int phip_vec_aypx(phip_ctx c, int32_t n, double *d_y, double alpha, c
 
 extern "C" int phip_vec_waxpy(phip_ctx c, int32_t n, double *d_w, double alpha, const double *d_x, const double *d_y)
 {
-  CHECK_CTX(c, "phip_vec_waxpy"); CHECK_N(n, "phip_vec_waxpy");
+  CHECK_CTX_Q(c, "phip_vec_waxpy"); CHECK_N(n, "phip_vec_waxpy");
   if (alpha == 1.0) return launch_ew<EW_WXPY, true, true, false>(c, n, d_w, d_x, d_y, NULL, 0, 0, 0);
   if (alpha == -1.0) return launch_ew<EW_WYMX, true, true, false>(c, n, d_w, d_x, d_y, NULL, 0, 0, 0);
   if (alpha == 0.0) return phip_vec_copy(c, n, d_y, d_w);
@@ -282,7 +416,7 @@ extern "C" int phip_vec_waxpy(phip_ctx c, int32_t n, double *d_w, double alpha, 
 
 extern "C" int phip_vec_axpby(phip_ctx c, int32_t n, double *d_y, double a, double b, const double *d_x)
 {
-  CHECK_CTX(c, "phip_vec_axpby"); CHECK_N(n, "phip_vec_axpby");
+  CHECK_CTX_Q(c, "phip_vec_axpby"); CHECK_N(n, "phip_vec_axpby");
   if (a == 0.0) return phip_vec_scale(c, n, d_y, b);       /* bvec1.c:107-108 */
   if (b == 1.0) return phip_vec_axpy(c, n, d_y, a, d_x);   /* :109-110 */
   if (a == 1.0) return phip_vec_aypx(c, n, d_y, b, d_x);   /* :111-112 */
@@ -292,7 +426,7 @@ extern "C" int phip_vec_axpby(phip_ctx c, int32_t n, double *d_y, double a, doub
 
 extern "C" int phip_vec_axpbypcz(phip_ctx c, int32_t n, double *d_z, double a, double b, double g, const double *d_x, const double *d_y)
 {
-  CHECK_CTX(c, "phip_vec_axpbypcz"); CHECK_N(n, "phip_vec_axpbypcz");
+  CHECK_CTX_Q(c, "phip_vec_axpbypcz"); CHECK_N(n, "phip_vec_axpbypcz");
   /* the four branches of bvec1.c:148-159 differ only in skipped multiplications by exactly 1 or 0 */
   if (g == 0.0) return launch_ew<EW_AXPBY, true, true, false>(c, n, d_z, d_x, d_y, NULL, a, b, 0);
   return launch_ew<EW_AXPBYPCZ, true, true, true>(c, n, d_z, d_x, d_y, d_z, a, b, g);
@@ -300,18 +434,30 @@ extern "C" int phip_vec_axpbypcz(phip_ctx c, int32_t n, double *d_z, double a, d
 
 extern "C" int phip_vec_pointwise_mult(phip_ctx c, int32_t n, double *d_w, const double *d_x, const double *d_y)
 {
-  CHECK_CTX(c, "phip_vec_pointwise_mult"); CHECK_N(n, "phip_vec_pointwise_mult");
+  CHECK_CTX_Q(c, "phip_vec_pointwise_mult"); CHECK_N(n, "phip_vec_pointwise_mult");
   return launch_ew<EW_PMULT, true, true, false>(c, n, d_w, d_x, d_y, NULL, 0, 0, 0); /* aliasing w==x / w==y is safe: pure elementwise */
 }
 
 extern "C" int phip_vec_pointwise_mult_reduce(phip_ctx c, int32_t n, double *d_w, const double *d_x, const double *d_y, int publish, phip_ticket *t)
 {
-  CHECK_CTX(c, "phip_vec_pointwise_mult_reduce"); CHECK_N(n, "phip_vec_pointwise_mult_reduce");
+  CHECK_CTX_Q(c, "phip_vec_pointwise_mult_reduce"); CHECK_N(n, "phip_vec_pointwise_mult_reduce");
   PHIP_REQUIRE(t, PHIP_ERR_ARG_NULL, "phip_vec_pointwise_mult_reduce: null ticket");
   PHIP_REQUIRE((d_w != d_x && d_w != d_y) || !n, PHIP_ERR_ARG_WRONG, "phip_vec_pointwise_mult_reduce: w must not alias x or y (use phip_vec_pointwise_mult)");
   RedCtl ctl;
   int    rc = phip_ticket_open(c, 3, publish, t, &ctl);
   if (rc) return rc;
+  if (n && c->ew_n && ew_can_join(c, n, d_w, d_x, d_y, NULL)) { /* the pending operations and this one leave together */
+    EwBatch B;
+    B.nops = c->ew_n + 1;
+    for (int k = 0; k < c->ew_n; k++) B.op[k] = c->ew[k];
+    phip_ctx_s::phip_ew_op &o = B.op[c->ew_n];
+    o.op = EW_PMULT; o.hx = 1; o.hy = 1; o.hz = 0; o.out = d_w; o.x = d_x; o.y = d_y; o.z = NULL; o.a = o.b = o.g = 0.0;
+    c->ew_n = 0;
+    hipLaunchKernelGGL((ew_batch_kernel<true>), dim3(phip_grid_for((int64_t)n / 2 + 1, 4, PHIP_RED_GRID)), dim3(PHIP_THREADS), 0, c->stream, n, B, ctl);
+    PHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  PHIP_FLUSH(c);
   hipLaunchKernelGGL(pmult_reduce_kernel, dim3(phip_grid_for((int64_t)n / 2 + 1, 4, PHIP_RED_GRID)), dim3(PHIP_THREADS), 0, c->stream, n, d_w, d_x, d_y, ctl);
   PHIP_CHECK_HIP(hipGetLastError());
   return 0;
@@ -319,13 +465,13 @@ extern "C" int phip_vec_pointwise_mult_reduce(phip_ctx c, int32_t n, double *d_w
 
 extern "C" int phip_vec_pointwise_divide(phip_ctx c, int32_t n, double *d_w, const double *d_x, const double *d_y)
 {
-  CHECK_CTX(c, "phip_vec_pointwise_divide"); CHECK_N(n, "phip_vec_pointwise_divide");
+  CHECK_CTX_Q(c, "phip_vec_pointwise_divide"); CHECK_N(n, "phip_vec_pointwise_divide");
   return launch_ew<EW_PDIV, true, true, false>(c, n, d_w, d_x, d_y, NULL, 0, 0, 0);
 }
 
 extern "C" int phip_vec_reciprocal(phip_ctx c, int32_t n, double *d_x)
 {
-  CHECK_CTX(c, "phip_vec_reciprocal"); CHECK_N(n, "phip_vec_reciprocal");
+  CHECK_CTX_Q(c, "phip_vec_reciprocal"); CHECK_N(n, "phip_vec_reciprocal");
   return launch_ew<EW_RECIP, true, false, false>(c, n, d_x, d_x, NULL, NULL, 0, 0, 0);
 }
 

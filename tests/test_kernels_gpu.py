@@ -530,3 +530,63 @@ def test_byproduct_tickets(ctx, orc):
     np.testing.assert_array_equal(vals, [32.0, 16.0, 32.0])
     for p in (dx, dy, dw):
         ctx.free(p)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 1000, 300001])
+def test_batched_elementwise_ops(orc, n):
+    """Elementwise operations wait in the context and leave in one launch (up to 4, call order kept per entry).  Chains in which each
+    operation reads what the previous one wrote, operands that alias, sub-vectors that overlap without being equal (must not share a
+    batch), different lengths, the reducing pointwise product joining a batch: same bits as unbatched execution (PHIP_EW_BATCH=0),
+    oracle within round-off."""
+    import ctypes as C
+    from petsc_amd import capi
+    from petsc_amd.capi import Ticket
+    rng = np.random.default_rng(77)
+    x0, y0, z0, w0 = (rng.standard_normal(n) for _ in range(4))
+
+    def run(c):
+        L = c.lib
+        dx, dy, dz, dw = c.to_device(x0), c.to_device(y0), c.to_device(z0), c.to_device(w0)
+        big = c.to_device(np.arange(2.0 * n + 8))
+        c.check(L.phip_vec_axpy(c.h, n, dy, 0.5, dx))              # y += 0.5 x
+        c.check(L.phip_vec_pointwise_mult(c.h, n, dw, dx, dy))     # w = x .* y        (reads the new y)
+        c.check(L.phip_vec_aypx(c.h, n, dz, -2.0, dw))             # z = w - 2 z       (reads the new w)
+        c.check(L.phip_vec_axpbypcz(c.h, n, dx, 2.0, 3.0, 0.5, dz, dw))  # x = 2 z + 3 w + 0.5 x
+        c.check(L.phip_vec_scale(c.h, n, dx, 1.25))                # fifth operation: the first four leave before it
+        c.check(L.phip_vec_waxpy(c.h, n, dw, -1.0, dx, dx))        # w = x - x = 0     (x twice, w rewritten)
+        c.check(L.phip_vec_pointwise_mult(c.h, n, dy, dy, dy))     # y = y .* y        (all three alias)
+        t = Ticket()
+        c.check(L.phip_vec_pointwise_mult_reduce(c.h, n, dw, dy, dz, 1, C.byref(t)))  # joins the batch: w = y .* z + sums
+        red = np.zeros(3)
+        c.check(L.phip_ticket_wait(c.h, C.byref(t), red.ctypes.data_as(C.POINTER(C.c_double))))
+        # overlapping, unequal operands: big[0:n] and big[1:n+1]
+        b1 = C.c_void_p(big.value + 8)
+        c.check(L.phip_vec_axpy(c.h, n, big, 1.0, dz))             # big[0:n] += z
+        c.check(L.phip_vec_axpy(c.h, n, b1, 1.0, dz))              # big[1:n+1] += z   (must not run concurrently with the line above)
+        c.check(L.phip_vec_scale(c.h, n + 3, big, 2.0))            # another length
+        out = [c.to_host(p, n) for p in (dx, dy, dz, dw)] + [c.to_host(big, 2 * n + 8), red]
+        for p in (dx, dy, dz, dw, big):
+            c.free(p)
+        return out
+
+    c1 = capi.Context(0)
+    got = run(c1)
+    c1.close()
+    os.environ["PHIP_EW_BATCH"] = "0"
+    try:
+        c0 = capi.Context(0)
+    finally:
+        del os.environ["PHIP_EW_BATCH"]
+    ref = run(c0)
+    c0.close()
+    for a, b in zip(got[:5], ref[:5]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_allclose(got[5], ref[5], rtol=1e-13)
+    # and against numpy
+    x, y, z, w = x0.copy(), y0.copy(), z0.copy(), w0.copy()
+    y = y + 0.5 * x; w = x * y; z = w - 2.0 * z; x = 2.0 * z + 3.0 * w + 0.5 * x; x = 1.25 * x; w = x - x; y = y * y; w = y * z
+    for a, b in zip(got[:4], (x, y, z, w)):
+        assert np.abs(a - b).max() <= 1e-13 * max(1.0, np.abs(b).max())
+    big = np.arange(2.0 * n + 8); big[:n] += z; big[1:n + 1] += z; big[:n + 3] *= 2.0
+    np.testing.assert_array_equal(got[4], big)
+    assert np.abs(got[5] - np.array([w @ w, w @ y, w @ z])).max() <= 1e-12 * max(1.0, (w * w).sum(), np.abs(w * y).sum(), np.abs(w * z).sum())
