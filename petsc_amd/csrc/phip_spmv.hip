@@ -659,7 +659,10 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     /* slots requested per lane before the gathers start: 8 for long rows (27-point 192^3: 361.9 -> 349.7 us), 4 otherwise (rows of 7
        never fill a batch of 8: 27.1 -> 36.1 us); PHIP_SELL_UNROLL=4|8 overrides */
     static const int unroll_env = getenv("PHIP_SELL_UNROLL") ? atoi(getenv("PHIP_SELL_UNROLL")) : 0;
-    const int        unroll = unroll_env ? unroll_env : (A->sell_maxlen >= 16 ? 8 : 4);
+    /* the fused-dot variant needs ~100 registers with batches of 8 and loses more occupancy than the longer batches give back
+       (27-point 256^3 inside KSPCG: 926 us against 903 us with batches of 4).  Also tried and dropped: taking the fused dot's weight
+       x[r] from the row's own diagonal gather instead of a second load (256^3: 903 -> 967 us, the per-slot test costs more) */
+    const int        unroll = unroll_env ? unroll_env : ((A->sell_maxlen >= 16 && !DOT) ? 8 : 4);
 #define SELL_LAUNCH(NTv, STv) do { if (unroll == 8) SELL_LAUNCH2(NTv, STv, 8); else SELL_LAUNCH2(NTv, STv, 4); } while (0)
     if (nt && stage) SELL_LAUNCH(true, true);
     else if (nt) SELL_LAUNCH(true, false);

@@ -255,20 +255,39 @@ __global__ __launch_bounds__(PHIP_THREADS) void ew_batch_kernel(int32_t n, EwBat
   double            acc[3] = {0.0, 0.0, 0.0};
   const int64_t     n2 = n >> 1;
   const int64_t     stride = (int64_t)gridDim.x * PHIP_THREADS;
-  for (int64_t i = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; i < n2; i += stride) {
+  /* EW_UNROLL entries per thread and round: the loads of one operation for all of them are in flight together (an operation cannot start
+     before the previous one's stores: the compiler must assume that they alias) */
+  constexpr int EW_UNROLL = 4;
+  for (int64_t i0 = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; i0 < n2; i0 += EW_UNROLL * stride) {
     for (int k = 0; k < B.nops; k++) {
       const phip_ctx_s::phip_ew_op &o = B.op[k];
-      double2 xv = {0, 0}, yv = {0, 0}, zv = {0, 0}, r;
-      if (o.hx) xv = reinterpret_cast<const double2 *>(o.x)[i];
-      if (o.hy) yv = reinterpret_cast<const double2 *>(o.y)[i];
-      if (o.hz) zv = reinterpret_cast<const double2 *>(o.z)[i];
-      r.x = ew_apply_rt(o.op, o.a, o.b, o.g, xv.x, yv.x, zv.x);
-      r.y = ew_apply_rt(o.op, o.a, o.b, o.g, xv.y, yv.y, zv.y);
-      reinterpret_cast<double2 *>(o.out)[i] = r;
+      double2 xv[EW_UNROLL], yv[EW_UNROLL], zv[EW_UNROLL], r[EW_UNROLL];
+#pragma unroll
+      for (int u = 0; u < EW_UNROLL; u++) {
+        const int64_t i = i0 + u * stride;
+        xv[u] = yv[u] = zv[u] = make_double2(0.0, 0.0);
+        if (i < n2) {
+          if (o.hx) xv[u] = reinterpret_cast<const double2 *>(o.x)[i];
+          if (o.hy) yv[u] = reinterpret_cast<const double2 *>(o.y)[i];
+          if (o.hz) zv[u] = reinterpret_cast<const double2 *>(o.z)[i];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < EW_UNROLL; u++) {
+        const int64_t i = i0 + u * stride;
+        r[u].x = ew_apply_rt(o.op, o.a, o.b, o.g, xv[u].x, yv[u].x, zv[u].x);
+        r[u].y = ew_apply_rt(o.op, o.a, o.b, o.g, xv[u].y, yv[u].y, zv[u].y);
+        if (i < n2) reinterpret_cast<double2 *>(o.out)[i] = r[u];
+      }
       if (RED && k == B.nops - 1) {
-        acc[0] += r.x * r.x + r.y * r.y;
-        acc[1] += r.x * xv.x + r.y * xv.y;
-        acc[2] += r.x * yv.x + r.y * yv.y;
+#pragma unroll
+        for (int u = 0; u < EW_UNROLL; u++) {
+          if (i0 + u * stride < n2) { /* entry order i0, i0 + stride, ...: the order of the one-entry-per-round loop */
+            acc[0] += r[u].x * r[u].x + r[u].y * r[u].y;
+            acc[1] += r[u].x * xv[u].x + r[u].y * xv[u].y;
+            acc[2] += r[u].x * yv[u].x + r[u].y * yv[u].y;
+          }
+        }
       }
     }
   }
@@ -453,7 +472,9 @@ extern "C" int phip_vec_pointwise_mult_reduce(phip_ctx c, int32_t n, double *d_w
     phip_ctx_s::phip_ew_op &o = B.op[c->ew_n];
     o.op = EW_PMULT; o.hx = 1; o.hy = 1; o.hz = 0; o.out = d_w; o.x = d_x; o.y = d_y; o.z = NULL; o.a = o.b = o.g = 0.0;
     c->ew_n = 0;
-    hipLaunchKernelGGL((ew_batch_kernel<true>), dim3(phip_grid_for((int64_t)n / 2 + 1, 4, PHIP_RED_GRID)), dim3(PHIP_THREADS), 0, c->stream, n, B, ctl);
+    static const int red_grid_env = getenv("PHIP_EW_RED_GRID") ? atoi(getenv("PHIP_EW_RED_GRID")) : 0;
+    const int        red_grid = (red_grid_env > 0 && red_grid_env <= PHIP_RED_BLOCKS) ? red_grid_env : PHIP_RED_GRID;
+    hipLaunchKernelGGL((ew_batch_kernel<true>), dim3(phip_grid_for((int64_t)n / 2 + 1, 4, red_grid)), dim3(PHIP_THREADS), 0, c->stream, n, B, ctl);
     PHIP_CHECK_HIP(hipGetLastError());
     return 0;
   }
