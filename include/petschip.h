@@ -129,7 +129,13 @@ int phip_mat_set_x_staging(phip_mat A, int on);
 int phip_mat_set_threads_per_row(phip_mat A, int32_t tpr);
 
 /* ---- vector kernels (the _VecOps slots, include/petsc/private/vecimpl.h:20-96) --------------------
- * n = local length.  Results of reductions are written to host memory and are valid on return. */
+ * n = local length.  Results of reductions are written to host memory and are valid on return.
+ * The elementwise operations (axpy ... reciprocal, set) are asynchronous like every launch, and in addition DEFERRED: they wait in the
+ * context until another entry point of this library needs the stream (every one of them launches what is pending first, including
+ * phip_sync, the copies, phip_free and phip_stream), and up to four of them leave in one launch that applies them in call order to each
+ * entry -- same bits as one launch per operation, fewer launches, operands re-read from cache (PHIP_EW_BATCH=0 in the environment
+ * switches the deferral off).  A caller that touches the vectors outside this library asks for phip_stream() or phip_sync() first, as it
+ * must for any asynchronous launch. */
 int phip_vec_dot(phip_ctx ctx, int32_t n, const double *d_x, const double *d_y, double *h_z);        /* VecDot_Seq/VecTDot_Seq bvec1.c:12-51 */
 int phip_vec_norm(phip_ctx ctx, int32_t n, const double *d_x, int type, double *h_z);                /* VecNorm_Seq bvec2.c:233-271 (h_z[2] for 1_AND_2) */
 int phip_vec_mdot(phip_ctx ctx, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *h_z); /* VecMDot_Seq dvec2.c:98-294 */
