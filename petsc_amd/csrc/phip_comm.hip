@@ -40,6 +40,7 @@ struct RcclApi {
   decltype(&ncclGetUniqueId)   GetUniqueId;
   decltype(&ncclCommInitRank)  CommInitRank;
   decltype(&ncclCommDestroy)   CommDestroy;
+  decltype(&ncclCommAbort)     CommAbort; /* optional */
   decltype(&ncclAllReduce)     AllReduce;
   decltype(&ncclAllGather)     AllGather;
   decltype(&ncclSend)          Send;
@@ -65,6 +66,7 @@ static int rccl_load(void)
   RESOLVE(GetUniqueId, "ncclGetUniqueId");
   RESOLVE(CommInitRank, "ncclCommInitRank");
   RESOLVE(CommDestroy, "ncclCommDestroy");
+  g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(h, "ncclCommAbort");
   RESOLVE(AllReduce, "ncclAllReduce");
   RESOLVE(AllGather, "ncclAllGather");
   RESOLVE(Send, "ncclSend");
@@ -270,13 +272,28 @@ extern "C" int phip_comm_unique_id(void *id128)
   return 0;
 }
 
-extern "C" int phip_comm_create(phip_ctx ctx, const char *backend, const void *id128, int nranks, int rank, phip_comm *out)
+/* everything a communicator holds; failed: the peers may be gone, so the RCCL communicator is aborted rather than destroyed */
+static void comm_release(phip_comm c, bool failed)
 {
-  PHIP_REQUIRE(ctx && backend && out, PHIP_ERR_ARG_NULL, "phip_comm_create: null argument");
-  PHIP_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: rank %d of %d", rank, nranks);
-  phip_comm c = new phip_comm_s();
-  c->ctx = ctx; c->rank = rank; c->size = nranks; c->nccl = NULL; c->tg = NULL; c->tg_key = 0;
-  memset(&c->hr, 0, sizeof(c->hr)); c->d_stage = NULL;
+  if (c->nccl) {
+    hipSetDevice(c->ctx->device);
+    if (!failed) {
+      hipStreamSynchronize(c->ctx->stream);
+      hipStreamSynchronize(c->ctx->comm_stream);
+      g_rccl.CommDestroy(c->nccl);
+    } else if (g_rccl.CommAbort) g_rccl.CommAbort(c->nccl);
+  }
+  if (c->d_stage) hipFree(c->d_stage);
+  hr_detach(c);
+  if (c->tg) {
+    std::lock_guard<std::mutex> lk(g_groups_mutex);
+    if (--c->tg->refs == 0) { g_groups.erase(c->tg_key); free(c->tg->hr_mem); delete c->tg; }
+  }
+  delete c;
+}
+
+static int comm_create_fill(phip_comm c, phip_ctx ctx, const char *backend, const void *id128, int nranks, int rank)
+{
   if (!strcmp(backend, "self")) {
     PHIP_REQUIRE(nranks == 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: backend self needs nranks 1");
     c->backend = BACKEND_SELF;
@@ -284,7 +301,7 @@ extern "C" int phip_comm_create(phip_ctx ctx, const char *backend, const void *i
     PHIP_REQUIRE(id128, PHIP_ERR_ARG_NULL, "phip_comm_create: rccl backend needs the unique id");
     PHIP_NEED_DEVICE(ctx, "phip_comm_create(rccl)");
     int rc = rccl_load();
-    if (rc) { delete c; return rc; }
+    if (rc) return rc;
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     PHIP_CHECK_HIP(hipSetDevice(ctx->device));
@@ -340,16 +357,25 @@ extern "C" int phip_comm_create(phip_ctx ctx, const char *backend, const void *i
         g->hr_mem = aligned_alloc(64, hr_bytes(nranks));
         memset(g->hr_mem, 0, hr_bytes(nranks));
       }
-      PHIP_REQUIRE(g->n == nranks, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: thread group size mismatch");
       g->refs++;
-      c->tg = g;
+      c->tg = g; /* from here comm_release lets go of the group */
+      PHIP_REQUIRE(g->n == nranks, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: thread group size mismatch");
       c->hr.slots = (HostRingSlot *)g->hr_mem; c->hr.bytes = hr_bytes(nranks); c->hr.round = 0; c->hr.is_shm = 0;
     }
     c->backend = BACKEND_THREADS;
-  } else {
-    delete c;
-    PHIP_REQUIRE(0, PHIP_ERR_SUP, "phip_comm_create: unknown backend '%s'", backend);
-  }
+  } else PHIP_REQUIRE(0, PHIP_ERR_SUP, "phip_comm_create: unknown backend '%s'", backend);
+  return 0;
+}
+
+extern "C" int phip_comm_create(phip_ctx ctx, const char *backend, const void *id128, int nranks, int rank, phip_comm *out)
+{
+  PHIP_REQUIRE(ctx && backend && out, PHIP_ERR_ARG_NULL, "phip_comm_create: null argument");
+  PHIP_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, PHIP_ERR_ARG_OUTOFRANGE, "phip_comm_create: rank %d of %d", rank, nranks);
+  phip_comm c = new phip_comm_s();
+  c->ctx = ctx; c->rank = rank; c->size = nranks; c->nccl = NULL; c->tg = NULL; c->tg_key = 0; c->backend = BACKEND_SELF;
+  memset(&c->hr, 0, sizeof(c->hr)); c->d_stage = NULL;
+  const int rc = comm_create_fill(c, ctx, backend, id128, nranks, rank);
+  if (rc) { comm_release(c, true); return rc; }
   *out = c;
   return 0;
 }
@@ -370,19 +396,7 @@ extern "C" int phip_comm_create_callbacks(phip_ctx ctx, int nranks, int rank, ph
 extern "C" int phip_comm_destroy(phip_comm c)
 {
   if (!c) return 0;
-  if (c->backend == BACKEND_RCCL && c->nccl) {
-    hipSetDevice(c->ctx->device);
-    hipStreamSynchronize(c->ctx->stream);
-    hipStreamSynchronize(c->ctx->comm_stream);
-    g_rccl.CommDestroy(c->nccl);
-    hipFree(c->d_stage);
-  }
-  hr_detach(c);
-  if (c->backend == BACKEND_THREADS) {
-    std::lock_guard<std::mutex> lk(g_groups_mutex);
-    if (--c->tg->refs == 0) { g_groups.erase(c->tg_key); free(c->tg->hr_mem); delete c->tg; }
-  }
-  delete c;
+  comm_release(c, false);
   return 0;
 }
 
