@@ -127,6 +127,17 @@ int phip_mat_format_info(phip_mat A, int *format, int32_t *ndiagonals, int64_t *
 int phip_mat_set_x_staging(phip_mat A, int on);
 /* tuning: threads_per_row (0 = auto), 1,2,4,...,64 */
 int phip_mat_set_threads_per_row(phip_mat A, int32_t tpr);
+/* Hot-column order of the CSR row-block layout, for irregular matrices whose x is far larger than L2 and whose columns are used very
+ * unevenly (power-law graphs; BASELINE config 5): the columns are numbered by descending use, x is copied into that order by every
+ * product (20 B per column) and the gathers then find the often-used entries sharing cache lines.  The nonzeros stay where they are,
+ * so every row adds the same products in the same order: same bits as without (the reference has no counterpart; its closest relative
+ * is a MatPermute by the user, which changes the operator seen by the solver, this does not).  Built at phip_mat_create when
+ * 8 n >= 48 MiB and the share of gathers that fall into the 32768 hottest lines of x rises by >= 0.04 (mode 1, the default;
+ * PHIP_HOT_COLUMNS or phip_set_default_hot_columns: 0 never, 2 whenever there are nonzeros); phip_mat_set_hot_columns switches an
+ * order that was built off and on. */
+int phip_set_default_hot_columns(int mode);
+int phip_mat_set_hot_columns(phip_mat A, int on);
+int phip_mat_hot_columns_info(phip_mat A, int *built, int *in_use, double *share_before, double *share_after);
 
 /* ---- vector kernels (the _VecOps slots, include/petsc/private/vecimpl.h:20-96) --------------------
  * n = local length.  Results of reductions are written to host memory and are valid on return.

@@ -43,6 +43,7 @@
 #define SELL_STAGE_MAX_BYTES (64 * 1024)
 
 static int g_default_fmt = 0; /* phip_set_default_mat_format */
+static int g_hot_mode = -1;   /* phip_set_default_hot_columns; -1: take PHIP_HOT_COLUMNS or 1 at the first matrix */
 
 struct phip_mat_s {
   phip_ctx ctx;
@@ -75,6 +76,12 @@ struct phip_mat_s {
   /* operator of y = A^T x: a second matrix holding A^T row by row, built on request (phip_mat_transpose_setup) */
   phip_mat              T;
   std::vector<int32_t> *t_perm; /* entry k of A^T is entry t_perm[k] of A */
+  /* hot-column order (row-block layout, x larger than the caches, skewed column use): see setup_hot */
+  int      hot_built, hot_on;
+  int32_t *d_hcol;   /* [nnz + pad] column indices in the hot order */
+  int32_t *d_horder; /* [n] x'[k] = x[horder[k]] */
+  double  *d_hx;     /* [n] x in the hot order, refilled by every product */
+  double   hot_share[2]; /* share of the gathers that fall into the hottest HOT_LINES lines of x, before / after */
 };
 
 /* Matrix entries are read once per launch.  When the matrix is much larger than the 256 MiB Infinity Cache, non-temporal loads keep
@@ -344,6 +351,75 @@ __global__ void getdiag_kernel(int32_t m, const int32_t *__restrict__ rowptr, co
   v[i] = d;
 }
 
+/* ---- hot-column order --------------------------------------------------------------------------------------------------------------
+   An irregular matrix whose x does not fit L2 pays for every gather that misses with a 128-byte line from the Infinity Cache or HBM,
+   and the product runs at the rate of those line fetches, not of the 12 B/nonzero matrix stream (DESIGN.md section 3, R-MAT).  Power-law
+   matrices use few columns very often.  Numbering the columns by descending use puts the hot entries of x side by side, so the lines
+   L2 keeps hold 16 hot entries each instead of one hot entry and its cold neighbours: x' = x[order] (one pass of 20 B per column per
+   product), column indices renumbered, nonzeros left where they are -- every row adds the same products in the same order, so the
+   result keeps its bits.  Measured, R-MAT scale 24 (x = 128 MiB): 3407 -> 2110 us + the pass over x; no gain while x is within reach of
+   L2 (scale 22, 32 MiB: 503 -> 482 us, less than the pass costs), hence the size threshold.  Built when the share of gathers that land
+   in the hottest HOT_LINES lines (one XCD's L2) rises by HOT_MIN_GAIN; PHIP_HOT_COLUMNS / phip_set_default_hot_columns: 0 never, 1 by that rule, 2 whenever the matrix has nonzeros. */
+#define HOT_LINES 32768
+#define HOT_MIN_BYTES (48ll << 20)
+#define HOT_MIN_GAIN 0.04
+
+__global__ __launch_bounds__(256) void hot_gather_kernel(int32_t n, const int32_t *__restrict__ order, const double *__restrict__ x, double *__restrict__ xp)
+{
+  for (int32_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) xp[k] = x[order[k]];
+}
+
+static double hot_line_share(const int32_t *cols, int64_t nnz, int32_t n, const int32_t *newcol)
+{
+  std::vector<int64_t> lc(((size_t)n + 15) / 16, 0);
+  for (int64_t k = 0; k < nnz; k++) lc[(size_t)((newcol ? newcol[cols[k]] : cols[k]) >> 4)]++;
+  if (lc.size() > HOT_LINES) std::nth_element(lc.begin(), lc.begin() + HOT_LINES, lc.end(), [](int64_t a, int64_t b) { return a > b; });
+  int64_t top = 0;
+  for (size_t q = 0; q < lc.size() && q < HOT_LINES; q++) top += lc[q];
+  return nnz ? (double)top / (double)nnz : 0.0;
+}
+
+static void free_hot(phip_mat A)
+{
+  if (A->ctx->device >= 0) { hipFree(A->d_hcol); hipFree(A->d_horder); hipFree(A->d_hx); }
+  A->d_hcol = NULL; A->d_horder = NULL; A->d_hx = NULL; A->hot_built = 0; A->hot_on = 0;
+}
+
+static int setup_hot(phip_mat A, const int32_t *h_j)
+{
+  free_hot(A);
+  if (g_hot_mode < 0) g_hot_mode = getenv("PHIP_HOT_COLUMNS") ? atoi(getenv("PHIP_HOT_COLUMNS")) : 1;
+  const int mode = g_hot_mode;
+  if (A->ctx->device < 0 || mode == 0 || A->nnz == 0 || A->n == 0 || A->sell_on) return 0;
+  if (mode != 2 && (int64_t)sizeof(double) * A->n < HOT_MIN_BYTES) return 0;
+  const int32_t n = A->n;
+  /* columns by descending use, ties by ascending index: a counting sort over the use counts */
+  std::vector<int32_t> cnt((size_t)n, 0), order((size_t)n), newcol((size_t)n);
+  for (int64_t k = 0; k < A->nnz; k++) cnt[(size_t)h_j[k]]++;
+  {
+    int32_t maxc = 0;
+    for (int32_t c = 0; c < n; c++) maxc = std::max(maxc, cnt[(size_t)c]);
+    std::vector<int64_t> start((size_t)maxc + 2, 0);
+    for (int32_t c = 0; c < n; c++) start[(size_t)(maxc - cnt[(size_t)c]) + 1]++;
+    for (size_t q = 1; q < start.size(); q++) start[q] += start[q - 1];
+    for (int32_t c = 0; c < n; c++) { const int32_t k = (int32_t)start[(size_t)(maxc - cnt[(size_t)c])]++; order[(size_t)k] = c; newcol[(size_t)c] = k; }
+  }
+  A->hot_share[0] = hot_line_share(h_j, A->nnz, n, NULL);
+  A->hot_share[1] = hot_line_share(h_j, A->nnz, n, newcol.data());
+  if (mode != 2 && A->hot_share[1] - A->hot_share[0] < HOT_MIN_GAIN) return 0;
+  std::vector<int32_t> hj((size_t)A->nnz + 8, 0);
+  for (int64_t k = 0; k < A->nnz; k++) hj[(size_t)k] = newcol[(size_t)h_j[k]];
+  hipStream_t st = A->ctx->stream;
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_hcol, sizeof(int32_t) * hj.size()));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_horder, sizeof(int32_t) * (size_t)n));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_hx, sizeof(double) * (size_t)n));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_hcol, hj.data(), sizeof(int32_t) * hj.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_horder, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipStreamSynchronize(st));
+  A->hot_built = 1; A->hot_on = 1;
+  return 0;
+}
+
 /* ---- host: row-block plan ---------------------------------------------------------------------- */
 static uint8_t choose_tpr_log2(int nrows, int maxlen)
 {
@@ -593,6 +669,7 @@ extern "C" int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t
   int rc = upload_plan(A);
   if (rc) return rc;
   if ((rc = setup_sell(A, h_j, h_a))) return rc;
+  if ((rc = setup_hot(A, h_j))) return rc;
   *out = A;
   return 0;
 }
@@ -629,6 +706,7 @@ extern "C" int phip_mat_destroy(phip_mat A)
   hipSetDevice(A->ctx->device);
   hipStreamSynchronize(A->ctx->stream);
   free_sell(A);
+  free_hot(A);
   delete A->h_sptr;
   hipFree(A->d_rowptr); hipFree(A->d_ridx); hipFree(A->d_col); hipFree(A->d_val); hipFree(A->d_blkrow); hipFree(A->d_blktpr);
   delete A->h_rowptr; delete A->h_blkrow; delete A->h_blktpr;
@@ -677,12 +755,19 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     /* out-of-cache irregular matrices: non-temporal matrix stream (R-MAT scale 22: 546 -> 505 us); PHIP_CSR_NT=0/1 overrides */
     static const int csr_nt_env = getenv("PHIP_CSR_NT") ? atoi(getenv("PHIP_CSR_NT")) : -1;
     const bool       csr_nt = csr_nt_env >= 0 ? csr_nt_env != 0 : (12 * A->nnz > PHIP_NT_MATRIX_BYTES && !A->use_cprow);
+    const int32_t   *cols = A->d_col;
+    const double    *xs = d_x;
+    if (A->hot_on && A->nblocks) { /* x in the hot-column order (setup_hot) */
+      const unsigned g = (unsigned)std::min<int64_t>(((int64_t)A->n + 1023) / 1024, 16384);
+      hipLaunchKernelGGL(hot_gather_kernel, dim3(g), dim3(256), 0, st, A->n, A->d_horder, d_x, A->d_hx);
+      cols = A->d_hcol; xs = A->d_hx;
+    }
     if (csr_nt)
-      hipLaunchKernelGGL((spmv_rowblock_kernel<DOT, true>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->nblocks, A->d_blkrow, A->d_blktpr, A->d_rowptr, A->d_ridx, A->d_col,
-                         A->d_val, d_x, d_yin, d_yout, add, A->use_cprow, d_v, ctl);
+      hipLaunchKernelGGL((spmv_rowblock_kernel<DOT, true>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->nblocks, A->d_blkrow, A->d_blktpr, A->d_rowptr, A->d_ridx, cols,
+                         A->d_val, xs, d_yin, d_yout, add, A->use_cprow, d_v, ctl);
     else
-      hipLaunchKernelGGL((spmv_rowblock_kernel<DOT, false>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->nblocks, A->d_blkrow, A->d_blktpr, A->d_rowptr, A->d_ridx, A->d_col,
-                         A->d_val, d_x, d_yin, d_yout, add, A->use_cprow, d_v, ctl);
+      hipLaunchKernelGGL((spmv_rowblock_kernel<DOT, false>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->nblocks, A->d_blkrow, A->d_blktpr, A->d_rowptr, A->d_ridx, cols,
+                         A->d_val, xs, d_yin, d_yout, add, A->use_cprow, d_v, ctl);
   }
   PHIP_CHECK_HIP(hipGetLastError());
   return 0;
@@ -873,6 +958,34 @@ extern "C" int phip_mat_set_format(phip_mat A, int fmt)
   PHIP_REQUIRE(fmt != 2 || A->sell_built, PHIP_ERR_SUP, "phip_mat_set_format: no SELL-dict copy was built for this matrix");
   A->sell_on = (fmt != 1 && A->sell_built) ? 1 : 0;
   if (A->T) A->T->sell_on = (fmt != 1 && A->T->sell_built) ? 1 : 0;
+  return 0;
+}
+
+/* hot-column order of the row-block layout (setup_hot): on = 0 gathers from x as it is, 1 uses the order built at creation (error if
+   none was built: x small, columns used evenly, or SELL-dict layout).  info: built / in use / share of gathers in the hottest lines
+   before and after (0 if not evaluated). */
+extern "C" int phip_set_default_hot_columns(int mode)
+{
+  PHIP_REQUIRE(mode >= 0 && mode <= 2, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_default_hot_columns: %d (0 never, 1 when it pays, 2 always)", mode);
+  g_hot_mode = mode;
+  return 0;
+}
+
+extern "C" int phip_mat_set_hot_columns(phip_mat A, int on)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_set_hot_columns: null matrix");
+  PHIP_REQUIRE(!on || A->hot_built, PHIP_ERR_SUP, "phip_mat_set_hot_columns: no hot-column order was built for this matrix");
+  A->hot_on = on ? 1 : 0;
+  return 0;
+}
+
+extern "C" int phip_mat_hot_columns_info(phip_mat A, int *built, int *in_use, double *share_before, double *share_after)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_hot_columns_info: null matrix");
+  if (built) *built = A->hot_built;
+  if (in_use) *in_use = A->hot_on && !A->sell_on;
+  if (share_before) *share_before = A->hot_share[0];
+  if (share_after) *share_after = A->hot_share[1];
   return 0;
 }
 

@@ -287,6 +287,80 @@ def test_mult_transpose_shapes(ctx, orc):
     ctx.free(d); ctx.free(e); ctx.check(ctx.lib.phip_mat_destroy(A))
 
 
+def test_hot_column_order(ctx, orc):
+    """The hot-column order (columns numbered by descending use, x copied into that order by every product) leaves every product and
+    every summation order as it was: bit-identical results for mult, multadd, the fused dot, the transpose and the compressed-row
+    form; getdiagonal still reads the original columns; small matrices do not get the order unless it is forced."""
+    import ctypes as C
+    from petsc_amd import generators as G
+    from petsc_amd.capi import Ticket
+    L = ctx.lib
+    rng = np.random.default_rng(77)
+
+    def info(A):
+        b, u, s0, s1 = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        ctx.check(L.phip_mat_hot_columns_info(A, C.byref(b), C.byref(u), C.byref(s0), C.byref(s1)))
+        return b.value, u.value, s0.value, s1.value
+
+    ai, aj, aa = G.rmat(13)
+    n = len(ai) - 1
+    A = ctx.mat_create(n, n, ai, aj, aa)
+    assert info(A)[:2] == (0, 0)                      # default rule: x far too small
+    assert L.phip_mat_set_hot_columns(A, 1) != 0
+    ctx.check(L.phip_mat_destroy(A))
+    ctx.check(L.phip_set_default_hot_columns(2))
+    try:
+        # a rectangular compressed-row block (the off-diagonal block's shape), a matrix with a row longer than a row block, R-MAT
+        nz_rows = np.sort(rng.choice(500, 60, replace=False)).astype(np.int32)
+        ri = np.zeros(501, dtype=np.int32)
+        ri[nz_rows + 1] = rng.integers(1, 40, 60)
+        ri = np.cumsum(ri).astype(np.int32)
+        rj = np.concatenate([np.sort(rng.choice(3000, ri[r + 1] - ri[r], replace=False)) for r in range(500)]).astype(np.int32)
+        ra = rng.standard_normal(len(rj))
+        cp = (np.concatenate([[0], np.cumsum(np.diff(ri)[nz_rows])]).astype(np.int32), nz_rows)
+        li = np.array([0, 3, 5003, 5004], dtype=np.int32)
+        lj = np.concatenate([[0, 2, 5], np.arange(5000), [7]]).astype(np.int32)
+        la = rng.standard_normal(len(lj))
+        cases = [(ai, aj, aa, n, None), (ri, rj, ra, 3000, cp), (li, lj, la, 5000, None)]
+        for ci, cj, ca, ncols, cprow in cases:
+            m = len(ci) - 1
+            x, v, y0 = rng.standard_normal(ncols), rng.standard_normal(m), rng.standard_normal(m)
+            A = ctx.mat_create(m, ncols, ci, cj, ca, cprow)
+            built, used, s0, s1 = info(A)
+            assert (built, used) == (1, 1) and s1 >= s0 - 1e-15
+            ctx.check(L.phip_mat_transpose_setup(A, ci.ctypes.data_as(C.POINTER(C.c_int32)), cj.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                 ca.ctypes.data_as(C.POINTER(C.c_double))))
+            dx, dv, dy0 = ctx.to_device(x), ctx.to_device(v), ctx.to_device(y0)
+            dy, dz, dt, dd = (ctx.to_device(np.zeros(max(m, ncols))) for _ in range(4))
+            out = {}
+            for on in (1, 0):
+                ctx.check(L.phip_mat_set_hot_columns(A, on))
+                ctx.check(L.phip_mat_mult(A, dx, dy))
+                ctx.check(L.phip_mat_multadd(A, dx, dy0, dz))
+                t = Ticket()
+                val = np.zeros(1)
+                ctx.check(L.phip_mat_mult_dot(A, dx, dt, dv, 1, C.byref(t)))
+                ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t), val.ctypes.data_as(C.POINTER(C.c_double))))
+                y, z, yd = ctx.to_host(dy, m), ctx.to_host(dz, m), ctx.to_host(dt, m)
+                ctx.check(L.phip_mat_mult_transpose(A, dv, dt))
+                yt = ctx.to_host(dt, ncols)
+                ctx.check(L.phip_mat_getdiagonal(A, dd))
+                out[on] = (y, z, yd, val.copy(), yt, ctx.to_host(dd, m))
+            for a, b in zip(out[0], out[1]):
+                np.testing.assert_array_equal(a, b)
+            assert relerr(out[1][0], orc.matmult(ci, cj, ca, x)) <= 1e-12
+            for pz in (dx, dv, dy0, dy, dz, dt, dd):
+                ctx.free(pz)
+            ctx.check(L.phip_mat_destroy(A))
+        # the stencil layout has no use for it
+        si, sj, sa = G.laplace3d_7pt(12)
+        A = ctx.mat_create(len(si) - 1, len(si) - 1, si, sj, sa)
+        assert info(A)[:2] == (0, 0)
+        ctx.check(L.phip_mat_destroy(A))
+    finally:
+        ctx.check(L.phip_set_default_hot_columns(1))
+
+
 def test_plan_covers_rows(ctx):
     from petsc_amd import generators as G
     for ai, aj, aa in (G.laplace3d_7pt(20), G.rmat(12)):
