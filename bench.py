@@ -142,7 +142,13 @@ def main():
     del blk
     kernel_name = "spmv_sell_kernel" if f_.value == 2 else "spmv_rowblock_kernel"
     # bytes the chosen layout really streams per launch: SELL-dict 9 B per (padded) entry + 1 B row length + x + y (+ slice pointers)
-    layout_bytes = (9 * pad_.value + 17 * m + 8 * ((m + 511) // 512)) if f_.value == 2 else (12 * nzA + 20 * m + 4)
+    # (1 B per entry when the matrix has <= 256 distinct (diagonal, value) pairs: the pair dictionary)
+    vdb_, vdu_, vdn_ = C.c_int(), C.c_int(), C.c_int32()
+    L.phip_mat_value_dict_info(hA, C.byref(vdb_), C.byref(vdu_), C.byref(vdn_))
+    entry_bytes = 1 if vdu_.value else 9
+    layout_bytes = (entry_bytes * pad_.value + 17 * m + 8 * ((m + 511) // 512)) if f_.value == 2 else (12 * nzA + 20 * m + 4)
+    layout_name = ("SELL-dict, pair dictionary of %d (diagonal, value) pairs (1 B/nz)" % vdn_.value if vdu_.value else "SELL-dict (9 B/nz)") if f_.value == 2 \
+        else "CSR row blocks (12 B/nz)"
     spmv_bytes = 12 * nzA + 20 * m + 4
     spmv_add_bytes = (12 * nzB + 28 * mB) if nzB else 0
     iter_bytes = spmv_bytes + spmv_add_bytes + 136 * m
@@ -218,9 +224,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "bytes_per_launch": spmv_bytes, "avg_launch_us": round(b2b_ms * 1e3, 2),
-                         "layout": "SELL-dict (9 B/nz)" if f_.value == 2 else "CSR row blocks (12 B/nz)", "layout_bytes_per_launch": layout_bytes,
+                         "layout": layout_name, "layout_bytes_per_launch": layout_bytes,
                          "layout_GBps": round(layout_bytes / (b2b_ms * 1e-3) / 1e9, 1), "layout_frac": round(layout_bytes / (b2b_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "note": "achieved = ALGORITHMIC CSR bytes (12 nz + 20 m + 4, SURVEY.md 8d) / launch time; the SELL-dict layout streams fewer bytes (layout_*), and the 128^3 working set fits the 256 MiB Infinity Cache, so achieved can exceed the HBM peak",
+                         "note": "achieved = ALGORITHMIC CSR bytes (12 nz + 20 m + 4, SURVEY.md 8d) / launch time; the SELL-dict layout streams fewer bytes (layout_*: one byte per entry names diagonal and value when the matrix has <= 256 distinct pairs, lossless; PHIP_VALUE_DICT=0 streams the values, 9 B/nz), and the 128^3 working set fits the 256 MiB Infinity Cache, so achieved can exceed the HBM peak",
                          "how": "%d launches back to back between two hipEvents on the library's compute stream, best of 3 (rocprofv3 average of the same kernel: profiles/)" % reps,
                          "avg_launch_us_inside_cg_event_pairs": round(spmv_ms * 1e3, 2), "achievable_peak_note": "6.29 TB/s measured float4 copy (MI355X_MICROARCH.md)"},
             "final_rnorm": res["rnorm"], "setup_s": round(setup_s, 2),

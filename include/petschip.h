@@ -122,6 +122,15 @@ int phip_mat_plan_get(phip_mat A, int32_t *h_block_row /* nblocks+1 */);
 int phip_set_default_mat_format(int fmt);
 int phip_mat_set_format(phip_mat A, int fmt);
 int phip_mat_format_info(phip_mat A, int *format, int32_t *ndiagonals, int64_t *padded_entries);
+/* Pair dictionary of the SELL-dict layout.  Matrices assembled from constant-coefficient stencils hold few distinct values; when the
+ * stored entries form <= 256 distinct (diagonal, value bit pattern) pairs, one byte per entry names both and the kernel reads the
+ * value from a 256-entry table in LDS: 1 byte of HBM traffic per nonzero instead of 9.  Lossless: the table holds the doubles the
+ * caller stored (keyed on their bits), the sums run in the same order -- same bits as with streamed values.  Built at upload and
+ * rebuilt by phip_mat_update_values (a matrix that stops fitting goes back to streamed values).  phip_set_default_value_dict(0) /
+ * PHIP_VALUE_DICT=0: never build; phip_mat_set_value_dict switches a built dictionary off and on (A/B measurements, tests). */
+int phip_set_default_value_dict(int mode);
+int phip_mat_set_value_dict(phip_mat A, int on);
+int phip_mat_value_dict_info(phip_mat A, int *built, int *in_use, int32_t *npairs);
 /* tuning: SELL-dict kernel gathers x from LDS-staged contiguous segments (one per cluster of nearby diagonals) instead of through
  * L1/L2; same bits; measured slower on MI355X for 7- and 27-point stencils, hence off by default */
 int phip_mat_set_x_staging(phip_mat A, int on);

@@ -47,6 +47,9 @@ SIGNATURES = [
     ("phip_mat_set_format", C.c_int, [_vp, C.c_int]),
     ("phip_mat_set_x_staging", C.c_int, [_vp, C.c_int]),
     ("phip_mat_format_info", C.c_int, [_vp, C.POINTER(C.c_int), _pI, C.POINTER(C.c_int64)]),
+    ("phip_set_default_value_dict", C.c_int, [C.c_int]),
+    ("phip_mat_set_value_dict", C.c_int, [_vp, C.c_int]),
+    ("phip_mat_value_dict_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pI]),
     ("phip_set_default_hot_columns", C.c_int, [C.c_int]),
     ("phip_mat_set_hot_columns", C.c_int, [_vp, C.c_int]),
     ("phip_mat_hot_columns_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pD, _pD]),

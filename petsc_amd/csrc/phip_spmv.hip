@@ -73,6 +73,14 @@ struct phip_mat_s {
   int32_t *d_scl;     /* [ncl][3]: first offset of the cluster, start of its segment in LDS (doubles), segment length */
   int32_t *d_sldsoff; /* [256]: LDS index of x[row + diagonal] for local row 0, per diagonal code */
   std::vector<int64_t> *h_sptr;
+  /* pair dictionary of the SELL-dict layout (setup_pairs): one byte per stored entry names (diagonal, value) */
+  int      vd_built, vd_on;
+  int32_t  vd_npairs;
+  uint8_t *d_spcode;  /* [P] pair code per stored entry, laid out like scode */
+  int32_t *d_spoffs;  /* [256] diagonal of each pair */
+  double  *d_svtab;   /* [256] value of each pair */
+  std::vector<uint8_t> *h_scode; /* host copies of scode and soffs: phip_mat_update_values rebuilds the pairs from them */
+  std::vector<int32_t> *h_soffs;
   /* operator of y = A^T x: a second matrix holding A^T row by row, built on request (phip_mat_transpose_setup) */
   phip_mat              T;
   std::vector<int32_t> *t_perm; /* entry k of A^T is entry t_perm[k] of A */
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(int32_t nbl
    STAGE: the x entries a slice needs form a few contiguous segments (one per cluster of nearby diagonals: 9 for a 27-point stencil);
    the workgroup copies them into LDS with coalesced loads and gathers from there, so each x entry crosses L2 once per cluster
    instead of once per diagonal and the per-lane gathers no longer thrash L1. */
-template <bool NT, bool DOT, bool STAGE, int U>
+template <bool NT, bool DOT, bool STAGE, int U, bool VD>
 __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int32_t n, int32_t nslices, const int64_t *__restrict__ sptr, const uint8_t *__restrict__ slen,
                                                                  const double *__restrict__ sval, const uint8_t *__restrict__ scode,
                                                                  const int32_t *__restrict__ soffs, int noffs, const int32_t *__restrict__ scl, int ncl,
@@ -250,9 +258,11 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
 #pragma clang fp contract(off) /* multiply and add round separately, as the reference's compiled loop does (no FMA) */
   extern __shared__ __attribute__((aligned(16))) double xs[]; /* STAGE: the x segments */
   __shared__ int32_t offs[SELL_MAX_OFFS];                      /* diagonal (or, STAGE, LDS index) per code */
+  __shared__ double  vtab[VD ? SELL_MAX_OFFS : 1];             /* VD: the value of each (diagonal, value) pair; sval = that table in HBM */
   __shared__ double  lds[4];
   const int t = threadIdx.x;
   offs[t] = (t < noffs) ? soffs[t] : 0;
+  if (VD) vtab[t] = (t < noffs) ? sval[t] : 0.0;
   __syncthreads();
   double dacc = 0.0;
   for (int b = blockIdx.x; b < nslices; b += gridDim.x) {
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
     const int  l0 = act ? slen[r0] : 0, l1 = has1 ? slen[r0 + 1] : 0;
     const int  lm = l0 > l1 ? l0 : l1;
     const int64_t  base = sptr[b];
-    const double2 *vp = reinterpret_cast<const double2 *>(sval + base) + t;
+    const double2 *vp = reinterpret_cast<const double2 *>(sval + (VD ? 0 : base)) + t; /* VD: not used */
     const uchar2  *cp = reinterpret_cast<const uchar2 *>(scode + base) + t;
     const int      g0 = STAGE ? 2 * t : r0; /* STAGE: index into xs[] relative to the slice, else global row */
     const double  *xv = STAGE ? xs : x;
@@ -287,13 +297,17 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
       double2 v[U];
       uchar2  c[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) { v[u] = ld_stream<NT>(vp + (size_t)(s + u) * (SELL_H / 2)); c[u] = ld_stream<NT>(cp + (size_t)(s + u) * (SELL_H / 2)); }
+      for (int u = 0; u < U; u++) {
+        if (!VD) v[u] = ld_stream<NT>(vp + (size_t)(s + u) * (SELL_H / 2));
+        c[u] = ld_stream<NT>(cp + (size_t)(s + u) * (SELL_H / 2));
+      }
       double xa[U], xb[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const bool a0 = s + u < l0, a1 = s + u < l1;
         xa[u] = xv[a0 ? g0 + offs[c[u].x] : 0];
         xb[u] = xv[a1 ? g0 + 1 + offs[c[u].y] : 0];
+        if (VD) v[u] = make_double2(vtab[c[u].x], vtab[c[u].y]);
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -306,7 +320,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
       uchar2  c[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        if (s + u < lm) { v[u] = ld_stream<NT>(vp + (size_t)(s + u) * (SELL_H / 2)); c[u] = ld_stream<NT>(cp + (size_t)(s + u) * (SELL_H / 2)); }
+        if (s + u < lm) { if (!VD) v[u] = ld_stream<NT>(vp + (size_t)(s + u) * (SELL_H / 2)); c[u] = ld_stream<NT>(cp + (size_t)(s + u) * (SELL_H / 2)); }
         else { v[u] = make_double2(0.0, 0.0); c[u] = make_uchar2(0, 0); }
       }
       double xa[4], xb[4];
@@ -315,6 +329,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
         const bool a0 = s + u < l0, a1 = s + u < l1;
         xa[u] = xv[a0 ? g0 + offs[c[u].x] : 0];
         xb[u] = xv[a1 ? g0 + 1 + offs[c[u].y] : 0];
+        if (VD) v[u] = make_double2(vtab[c[u].x], vtab[c[u].y]);
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -527,8 +542,85 @@ static void fill_sell_values(const std::vector<int32_t> &rp, int32_t m, const do
     }
 }
 
+/* ---- pair dictionary -------------------------------------------------------------------------------------------------------------
+   A matrix assembled from a constant-coefficient stencil holds few distinct values: the 7-point Laplacian two, each on its own
+   diagonals.  When the stored entries of a SELL-dict matrix form at most 256 distinct (diagonal, value bit pattern) pairs, ONE byte
+   per entry names both, the two tables sit in LDS, and a nonzero costs 1 byte of HBM traffic instead of 9 (12 in CSR).  The value a
+   lane multiplies with is the table's copy of the very double the caller stored (keyed on its bits: -0.0, NaN payloads and
+   denormals survive), and the sums run as before, so the result keeps the reference's bits.  phip_mat_update_values rebuilds the
+   pairs; a matrix that stops fitting goes back to streamed values.  PHIP_VALUE_DICT=0 / phip_set_default_value_dict(0) never builds. */
+static int g_vd_mode = -1;
+
+static int build_pairs(const std::vector<uint8_t> &scode, const std::vector<double> &sval, int64_t P, const std::vector<int32_t> &soffs,
+                       std::vector<uint8_t> &pcode, std::vector<int32_t> &poffs, std::vector<double> &pvals)
+{
+  struct Slot { uint64_t bits; int32_t code; int32_t pair; };
+  const int        HB = 2048; /* open addressing, load <= 1/8 */
+  std::vector<Slot> tab((size_t)HB, Slot{0, -1, -1});
+  poffs.clear(); pvals.clear();
+  pcode.assign((size_t)P + 16, 0);
+  uint64_t lastbits = 0;
+  int      lastcode = -1, lastpair = 0;
+  for (int64_t p = 0; p < P; p++) {
+    uint64_t bits;
+    memcpy(&bits, &sval[(size_t)p], sizeof(bits));
+    const int code = scode[(size_t)p];
+    if (code == lastcode && bits == lastbits) { pcode[(size_t)p] = (uint8_t)lastpair; continue; }
+    size_t h = (size_t)((((bits * 0x9E3779B97F4A7C15ull) >> 40) ^ ((uint64_t)code * 0x9E37u)) & (uint64_t)(HB - 1));
+    for (;; h = (h + 1) & (HB - 1)) {
+      Slot &sl = tab[h];
+      if (sl.pair < 0) {
+        if (poffs.size() >= SELL_MAX_OFFS) return 0;
+        sl.bits = bits; sl.code = code; sl.pair = (int32_t)poffs.size();
+        poffs.push_back(soffs[(size_t)code]);
+        pvals.push_back(sval[(size_t)p]);
+        break;
+      }
+      if (sl.bits == bits && sl.code == code) break;
+    }
+    lastbits = bits; lastcode = code; lastpair = tab[h].pair;
+    pcode[(size_t)p] = (uint8_t)lastpair;
+  }
+  return 1;
+}
+
+static void free_pairs(phip_mat A)
+{
+  if (A->ctx->device >= 0) { hipFree(A->d_spcode); hipFree(A->d_spoffs); hipFree(A->d_svtab); }
+  A->d_spcode = NULL; A->d_spoffs = NULL; A->d_svtab = NULL; A->vd_built = 0; A->vd_on = 0; A->vd_npairs = 0;
+}
+
+/* scode / sval: the SELL-dict arrays on the host; soffs: the diagonal table (its first sell_noffs entries) */
+static int setup_pairs(phip_mat A, const std::vector<uint8_t> &scode, const std::vector<double> &sval, const std::vector<int32_t> &soffs)
+{
+  const int was_on = A->vd_built ? A->vd_on : 1;
+  if (g_vd_mode < 0) g_vd_mode = getenv("PHIP_VALUE_DICT") ? atoi(getenv("PHIP_VALUE_DICT")) : 1;
+  if (A->ctx->device < 0 || g_vd_mode == 0) { free_pairs(A); return 0; }
+  std::vector<uint8_t> pcode;
+  std::vector<int32_t> poffs;
+  std::vector<double>  pvals;
+  if (!build_pairs(scode, sval, A->sell_padded, soffs, pcode, poffs, pvals)) { free_pairs(A); return 0; }
+  hipStream_t st = A->ctx->stream;
+  if (!A->d_spcode) {
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_spcode, pcode.size()));
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_spoffs, sizeof(int32_t) * SELL_MAX_OFFS));
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_svtab, sizeof(double) * SELL_MAX_OFFS));
+  }
+  A->vd_npairs = (int32_t)poffs.size();
+  poffs.resize(SELL_MAX_OFFS, 0); pvals.resize(SELL_MAX_OFFS, 0.0);
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_spcode, pcode.data(), pcode.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_spoffs, poffs.data(), sizeof(int32_t) * SELL_MAX_OFFS, hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_svtab, pvals.data(), sizeof(double) * SELL_MAX_OFFS, hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipStreamSynchronize(st));
+  A->vd_built = 1; A->vd_on = was_on;
+  return 0;
+}
+
 static void free_sell(phip_mat A)
 {
+  free_pairs(A);
+  delete A->h_scode; A->h_scode = NULL;
+  delete A->h_soffs; A->h_soffs = NULL;
   if (A->ctx->device >= 0) { hipFree(A->d_sval); hipFree(A->d_scode); hipFree(A->d_slen); hipFree(A->d_sptr); hipFree(A->d_soffs); hipFree(A->d_scl); hipFree(A->d_sldsoff); }
   A->d_sval = NULL; A->d_scode = NULL; A->d_slen = NULL; A->d_sptr = NULL; A->d_soffs = NULL; A->d_scl = NULL; A->d_sldsoff = NULL; A->stage_ok = 0;
   A->sell_on = 0; A->sell_built = 0;
@@ -597,6 +689,11 @@ static int setup_sell(phip_mat A, const int32_t *h_j, const double *h_a)
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_scl, scl.data(), sizeof(int32_t) * scl.size(), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_sldsoff, sldsoff.data(), sizeof(int32_t) * SELL_MAX_OFFS, hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipStreamSynchronize(st));
+  int rc = setup_pairs(A, scode, sval, soffs);
+  if (rc) return rc;
+  A->h_scode = new std::vector<uint8_t>();
+  A->h_scode->swap(scode);
+  A->h_soffs = new std::vector<int32_t>(soffs);
   return 0;
 }
 
@@ -691,7 +788,7 @@ extern "C" int phip_mat_update_values(phip_mat A, const double *h_a)
     fill_sell_values(*A->h_rowptr, A->m, h_a, *A->h_sptr, sval);
     PHIP_CHECK_HIP(hipMemcpyAsync(A->d_sval, sval.data(), sizeof(double) * sval.size(), hipMemcpyHostToDevice, A->ctx->stream));
     PHIP_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
-    return 0;
+    return setup_pairs(A, *A->h_scode, sval, *A->h_soffs); /* the new values may form other pairs, or too many */
   }
   PHIP_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
   return 0;
@@ -725,15 +822,19 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     static const int dot_grid_env = getenv("PHIP_SPMV_DOT_GRID") ? atoi(getenv("PHIP_SPMV_DOT_GRID")) : 0;
     const int      dot_cap = (dot_grid_env > 0 && dot_grid_env <= PHIP_RED_BLOCKS) ? dot_grid_env : 1024;
     const unsigned grid = DOT ? (unsigned)(A->sell_nslices < dot_cap ? A->sell_nslices : dot_cap) : (unsigned)A->sell_nslices;
-    const bool     nt = 9 * A->sell_padded > PHIP_NT_MATRIX_BYTES;
+    const bool     vd = A->vd_built && A->vd_on;
+    const bool     nt = (vd ? 1 : 9) * A->sell_padded > PHIP_NT_MATRIX_BYTES;
     /* LDS staging of x is correct but measured SLOWER than gathering through L1/L2 (7-point 128^3: 26.9 -> 31.8 us; 27-point 160^3:
        206 -> 220 us): the gathers are not what bounds this kernel.  Off unless PHIP_SELL_STAGE=1. */
     static const int stage_env = getenv("PHIP_SELL_STAGE") ? atoi(getenv("PHIP_SELL_STAGE")) : 0;
-    const bool     stage = A->stage_ok && (stage_env != 0 || A->stage_user);
+    const bool     stage = A->stage_ok && (stage_env != 0 || A->stage_user) && !vd;
 #define SELL_LAUNCH2(NTv, STv, Uv)                                                                                                                        \
-  hipLaunchKernelGGL((spmv_sell_kernel<NTv, DOT, STv, Uv>), dim3(grid), dim3(PHIP_THREADS), (STv) ? sizeof(double) * (size_t)A->stage_lds_doubles : 0, st, A->m, \
+  hipLaunchKernelGGL((spmv_sell_kernel<NTv, DOT, STv, Uv, false>), dim3(grid), dim3(PHIP_THREADS), (STv) ? sizeof(double) * (size_t)A->stage_lds_doubles : 0, st, A->m, \
                      A->n, A->sell_nslices, A->d_sptr, A->d_slen, A->d_sval, A->d_scode, (STv) ? A->d_sldsoff : A->d_soffs, A->sell_noffs, A->d_scl,      \
                      A->stage_ncl, d_x, d_yin, d_yout, add, d_v, ctl)
+#define SELL_LAUNCH_VD(NTv, Uv)                                                                                                                           \
+  hipLaunchKernelGGL((spmv_sell_kernel<NTv, DOT, false, Uv, true>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_sptr, A->d_slen,   \
+                     A->d_svtab, A->d_spcode, A->d_spoffs, A->vd_npairs, A->d_scl, A->stage_ncl, d_x, d_yin, d_yout, add, d_v, ctl)
     /* slots requested per lane before the gathers start: 8 for long rows (27-point 192^3: 361.9 -> 349.7 us), 4 otherwise (rows of 7
        never fill a batch of 8: 27.1 -> 36.1 us); PHIP_SELL_UNROLL=4|8 overrides */
     static const int unroll_env = getenv("PHIP_SELL_UNROLL") ? atoi(getenv("PHIP_SELL_UNROLL")) : 0;
@@ -742,11 +843,16 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
        x[r] from the row's own diagonal gather instead of a second load (256^3: 903 -> 967 us, the per-slot test costs more) */
     const int        unroll = unroll_env ? unroll_env : ((A->sell_maxlen >= 16 && !DOT) ? 8 : 4);
 #define SELL_LAUNCH(NTv, STv) do { if (unroll == 8) SELL_LAUNCH2(NTv, STv, 8); else SELL_LAUNCH2(NTv, STv, 4); } while (0)
-    if (nt && stage) SELL_LAUNCH(true, true);
+    if (vd) {
+      if (nt) { if (unroll == 8) SELL_LAUNCH_VD(true, 8); else SELL_LAUNCH_VD(true, 4); }
+      else { if (unroll == 8) SELL_LAUNCH_VD(false, 8); else SELL_LAUNCH_VD(false, 4); }
+    }
+    else if (nt && stage) SELL_LAUNCH(true, true);
     else if (nt) SELL_LAUNCH(true, false);
     else if (stage) SELL_LAUNCH(false, true);
     else SELL_LAUNCH(false, false);
 #undef SELL_LAUNCH2
+#undef SELL_LAUNCH_VD
 #undef SELL_LAUNCH
   } else {
     static const int dot_grid_env = getenv("PHIP_SPMV_DOT_GRID") ? atoi(getenv("PHIP_SPMV_DOT_GRID")) : 0;
@@ -995,6 +1101,33 @@ extern "C" int phip_mat_format_info(phip_mat A, int *format, int32_t *ndiagonals
   if (format) *format = A->sell_on ? 2 : 1;
   if (ndiagonals) *ndiagonals = A->sell_built ? A->sell_noffs : 0;
   if (padded_entries) *padded_entries = A->sell_built ? A->sell_padded : 0;
+  return 0;
+}
+
+/* pair dictionary of the SELL-dict layout (setup_pairs): on = 0 streams the values, 1 uses the pairs built at upload (error if the
+   matrix has more than 256 distinct (diagonal, value) pairs or is not in the SELL-dict layout) */
+extern "C" int phip_set_default_value_dict(int mode)
+{
+  PHIP_REQUIRE(mode == 0 || mode == 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_default_value_dict: %d (0 never, 1 when the matrix allows)", mode);
+  g_vd_mode = mode;
+  return 0;
+}
+
+extern "C" int phip_mat_set_value_dict(phip_mat A, int on)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_set_value_dict: null matrix");
+  PHIP_REQUIRE(!on || A->vd_built, PHIP_ERR_SUP, "phip_mat_set_value_dict: no pair dictionary was built for this matrix");
+  A->vd_on = on ? 1 : 0;
+  if (A->T && A->T->vd_built) A->T->vd_on = A->vd_on;
+  return 0;
+}
+
+extern "C" int phip_mat_value_dict_info(phip_mat A, int *built, int *in_use, int32_t *npairs)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_value_dict_info: null matrix");
+  if (built) *built = A->vd_built;
+  if (in_use) *in_use = A->vd_built && A->vd_on && A->sell_on;
+  if (npairs) *npairs = A->vd_built ? A->vd_npairs : 0;
   return 0;
 }
 

@@ -287,6 +287,86 @@ def test_mult_transpose_shapes(ctx, orc):
     ctx.free(d); ctx.free(e); ctx.check(ctx.lib.phip_mat_destroy(A))
 
 
+def test_value_pair_dictionary(ctx, orc):
+    """SELL-dict matrices with <= 256 distinct (diagonal, value) pairs are read through one byte per entry: same bits as with
+    streamed values (and as the oracle), including -0.0 and denormal entries; phip_mat_update_values follows the values in and out
+    of the dictionary."""
+    import ctypes as C
+    from petsc_amd import generators as G
+    from petsc_amd.capi import Ticket
+    L = ctx.lib
+    rng = np.random.default_rng(5)
+
+    def info(A):
+        b, u, npairs = C.c_int(), C.c_int(), C.c_int32()
+        ctx.check(L.phip_mat_value_dict_info(A, C.byref(b), C.byref(u), C.byref(npairs)))
+        return b.value, u.value, npairs.value
+
+    def products(A, m, x, v, y0):
+        dx, dv, dy0 = ctx.to_device(x), ctx.to_device(v), ctx.to_device(y0)
+        dy, dz, dt = (ctx.to_device(np.zeros(m)) for _ in range(3))
+        ctx.check(L.phip_mat_mult(A, dx, dy))
+        ctx.check(L.phip_mat_multadd(A, dx, dy0, dz))
+        t = Ticket()
+        val = np.zeros(1)
+        ctx.check(L.phip_mat_mult_dot(A, dx, dt, dv, 1, C.byref(t)))
+        ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t), val.ctypes.data_as(C.POINTER(C.c_double))))
+        out = [ctx.to_host(dy, m), ctx.to_host(dz, m), ctx.to_host(dt, m), val.copy()]
+        ctx.check(L.phip_mat_mult_transpose(A, dv, dt))
+        out.append(ctx.to_host(dt, m))
+        for pz in (dx, dv, dy0, dy, dz, dt):
+            ctx.free(pz)
+        return out
+
+    cases = [G.laplace3d_7pt(24), G.box3d_27pt(17), G.convdiff3d_7pt(19, 13, 11), G.laplace2d_5pt(57, 31), G.laplace2d_5pt(1, 700)]
+    for ci, (ai, aj, aa) in enumerate(cases):
+        m = len(ai) - 1
+        aa = aa.copy()
+        if ci == 0:   # values whose bits matter: -0.0, a denormal, the largest double
+            aa[5], aa[77], aa[300] = -0.0, 5e-324, 1.7976931348623157e308
+        x, v, y0 = G.random_vector(m), rng.standard_normal(m), rng.standard_normal(m)
+        A = ctx.mat_create(m, m, ai, aj, aa)
+        built, used, npairs = info(A)
+        assert (built, used) == (1, 1) and 1 <= npairs <= 256
+        pi, pj, pa = (ai.ctypes.data_as(C.POINTER(C.c_int32)), aj.ctypes.data_as(C.POINTER(C.c_int32)), aa.ctypes.data_as(C.POINTER(C.c_double)))
+        ctx.check(L.phip_mat_transpose_setup(A, pi, pj, pa))
+        on = products(A, m, x, v, y0)
+        ctx.check(L.phip_mat_set_value_dict(A, 0))
+        assert info(A)[1] == 0
+        off = products(A, m, x, v, y0)
+        for a, b in zip(on, off):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(on[0], orc.matmult(ai, aj, aa, x))
+        ctx.check(L.phip_mat_set_value_dict(A, 1))
+        # values that no longer fit: the matrix goes back to streamed values, and returns to the dictionary when they fit again
+        many = aa * rng.uniform(0.5, 1.5, len(aa))
+        ctx.check(L.phip_mat_update_values(A, many.ctypes.data_as(C.POINTER(C.c_double))))
+        if len(aa) > 2000:
+            assert info(A)[:2] == (0, 0)
+            assert L.phip_mat_set_value_dict(A, 1) != 0
+        np.testing.assert_array_equal(products(A, m, x, v, y0)[0], orc.matmult(ai, aj, many, x))
+        few = np.round(many * 2.0) / 2.0 + 0.25
+        ctx.check(L.phip_mat_update_values(A, few.ctypes.data_as(C.POINTER(C.c_double))))
+        assert info(A)[:2] == (1, 1)
+        got = products(A, m, x, v, y0)
+        np.testing.assert_array_equal(got[0], orc.matmult(ai, aj, few, x))
+        np.testing.assert_array_equal(got[4], orc.matmulttranspose(ai, aj, few, m, v))
+        ctx.check(L.phip_mat_destroy(A))
+    # never built when switched off, nor for matrices outside the SELL-dict layout
+    ctx.check(L.phip_set_default_value_dict(0))
+    try:
+        ai, aj, aa = cases[0]
+        A = ctx.mat_create(len(ai) - 1, len(ai) - 1, ai, aj, aa)
+        assert info(A) == (0, 0, 0)
+        ctx.check(L.phip_mat_destroy(A))
+    finally:
+        ctx.check(L.phip_set_default_value_dict(1))
+    ai, aj, aa = G.rmat(12)
+    A = ctx.mat_create(len(ai) - 1, len(ai) - 1, ai, aj, aa)
+    assert info(A) == (0, 0, 0)
+    ctx.check(L.phip_mat_destroy(A))
+
+
 def test_hot_column_order(ctx, orc):
     """The hot-column order (columns numbered by descending use, x copied into that order by every product) leaves every product and
     every summation order as it was: bit-identical results for mult, multadd, the fused dot, the transpose and the compressed-row
