@@ -140,13 +140,13 @@ def main():
     L.phip_mat_format_info(hA, C.byref(f_), C.byref(nd_), C.byref(pad_))
     blk_m, blk_n = blk["m"], blk["n"]
     del blk
-    kernel_name = "spmv_sell_kernel" if f_.value == 2 else "spmv_rowblock_kernel"
     # bytes the chosen layout really streams per launch: SELL-dict 9 B per (padded) entry + 1 B row length + x + y (+ slice pointers)
     # (1 B per entry when the matrix has <= 256 distinct (diagonal, value) pairs: the pair dictionary)
     vdb_, vdu_, vdn_ = C.c_int(), C.c_int(), C.c_int32()
     L.phip_mat_value_dict_info(hA, C.byref(vdb_), C.byref(vdu_), C.byref(vdn_))
     entry_bytes = 1 if vdu_.value else 9
     layout_bytes = (entry_bytes * pad_.value + 17 * m + 8 * ((m + 511) // 512)) if f_.value == 2 else (12 * nzA + 20 * m + 4)
+    kernel_name = ("spmv_pair_kernel" if vdu_.value else "spmv_sell_kernel") if f_.value == 2 else "spmv_rowblock_kernel"
     layout_name = ("SELL-dict, pair dictionary of %d (diagonal, value) pairs (1 B/nz)" % vdn_.value if vdu_.value else "SELL-dict (9 B/nz)") if f_.value == 2 \
         else "CSR row blocks (12 B/nz)"
     spmv_bytes = 12 * nzA + 20 * m + 4

@@ -26,6 +26,11 @@
 // coalesced), looks the diagonals up in LDS, gathers x[row + diag] and accumulates ITS rows k-ascending from 0.0 (or y[i]) with
 // separately rounded multiply and add: again the arithmetic of PetscSparseDensePlusDot bit for bit.  The CSR arrays stay on the
 // device for MatGetDiagonal and as the source of truth.
+//
+// On top of it, when the stored entries form at most 256 distinct (diagonal, value) pairs -- matrices assembled from constant-
+// coefficient stencils -- a "pair dictionary": one byte per entry names both, the values come from a table in LDS and a nonzero costs
+// 1 byte of HBM traffic (setup_pairs, spmv_pair_kernel).  Lossless, same summation order, same bits.
+// For irregular matrices whose x outgrows L2 and whose columns are used very unevenly: the hot-column order (setup_hot).
 #include "phip_internal.h"
 #include "phip_reduce.h"
 #include <stdlib.h>
@@ -76,7 +81,9 @@ struct phip_mat_s {
   /* pair dictionary of the SELL-dict layout (setup_pairs): one byte per stored entry names (diagonal, value) */
   int      vd_built, vd_on;
   int32_t  vd_npairs;
-  uint8_t *d_spcode;  /* [P] pair code per stored entry, laid out like scode */
+  uint32_t *d_pgrp;   /* pair codes: [slice][group of 4 slots][row 0..511], one dword = the codes of 4 consecutive slots of a row */
+  int64_t  *d_pptr;   /* [S+1] first dword of each slice in d_pgrp */
+  int64_t   pgrp_dwords;
   int32_t *d_spoffs;  /* [256] diagonal of each pair */
   double  *d_svtab;   /* [256] value of each pair */
   std::vector<uint8_t> *h_scode; /* host copies of scode and soffs: phip_mat_update_values rebuilds the pairs from them */
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(int32_t nbl
    STAGE: the x entries a slice needs form a few contiguous segments (one per cluster of nearby diagonals: 9 for a 27-point stencil);
    the workgroup copies them into LDS with coalesced loads and gathers from there, so each x entry crosses L2 once per cluster
    instead of once per diagonal and the per-lane gathers no longer thrash L1. */
-template <bool NT, bool DOT, bool STAGE, int U, bool VD>
+template <bool NT, bool DOT, bool STAGE, int U>
 __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int32_t n, int32_t nslices, const int64_t *__restrict__ sptr, const uint8_t *__restrict__ slen,
                                                                  const double *__restrict__ sval, const uint8_t *__restrict__ scode,
                                                                  const int32_t *__restrict__ soffs, int noffs, const int32_t *__restrict__ scl, int ncl,
@@ -258,11 +265,9 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
 #pragma clang fp contract(off) /* multiply and add round separately, as the reference's compiled loop does (no FMA) */
   extern __shared__ __attribute__((aligned(16))) double xs[]; /* STAGE: the x segments */
   __shared__ int32_t offs[SELL_MAX_OFFS];                      /* diagonal (or, STAGE, LDS index) per code */
-  __shared__ double  vtab[VD ? SELL_MAX_OFFS : 1];             /* VD: the value of each (diagonal, value) pair; sval = that table in HBM */
   __shared__ double  lds[4];
   const int t = threadIdx.x;
   offs[t] = (t < noffs) ? soffs[t] : 0;
-  if (VD) vtab[t] = (t < noffs) ? sval[t] : 0.0;
   __syncthreads();
   double dacc = 0.0;
   for (int b = blockIdx.x; b < nslices; b += gridDim.x) {
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
     const int  l0 = act ? slen[r0] : 0, l1 = has1 ? slen[r0 + 1] : 0;
     const int  lm = l0 > l1 ? l0 : l1;
     const int64_t  base = sptr[b];
-    const double2 *vp = reinterpret_cast<const double2 *>(sval + (VD ? 0 : base)) + t; /* VD: not used */
+    const double2 *vp = reinterpret_cast<const double2 *>(sval + base) + t;
     const uchar2  *cp = reinterpret_cast<const uchar2 *>(scode + base) + t;
     const int      g0 = STAGE ? 2 * t : r0; /* STAGE: index into xs[] relative to the slice, else global row */
     const double  *xv = STAGE ? xs : x;
@@ -297,17 +302,13 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
       double2 v[U];
       uchar2  c[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        if (!VD) v[u] = ld_stream<NT>(vp + (size_t)(s + u) * (SELL_H / 2));
-        c[u] = ld_stream<NT>(cp + (size_t)(s + u) * (SELL_H / 2));
-      }
+      for (int u = 0; u < U; u++) { v[u] = ld_stream<NT>(vp + (size_t)(s + u) * (SELL_H / 2)); c[u] = ld_stream<NT>(cp + (size_t)(s + u) * (SELL_H / 2)); }
       double xa[U], xb[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const bool a0 = s + u < l0, a1 = s + u < l1;
         xa[u] = xv[a0 ? g0 + offs[c[u].x] : 0];
         xb[u] = xv[a1 ? g0 + 1 + offs[c[u].y] : 0];
-        if (VD) v[u] = make_double2(vtab[c[u].x], vtab[c[u].y]);
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
       uchar2  c[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        if (s + u < lm) { if (!VD) v[u] = ld_stream<NT>(vp + (size_t)(s + u) * (SELL_H / 2)); c[u] = ld_stream<NT>(cp + (size_t)(s + u) * (SELL_H / 2)); }
+        if (s + u < lm) { v[u] = ld_stream<NT>(vp + (size_t)(s + u) * (SELL_H / 2)); c[u] = ld_stream<NT>(cp + (size_t)(s + u) * (SELL_H / 2)); }
         else { v[u] = make_double2(0.0, 0.0); c[u] = make_uchar2(0, 0); }
       }
       double xa[4], xb[4];
@@ -329,7 +330,6 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
         const bool a0 = s + u < l0, a1 = s + u < l1;
         xa[u] = xv[a0 ? g0 + offs[c[u].x] : 0];
         xb[u] = xv[a1 ? g0 + 1 + offs[c[u].y] : 0];
-        if (VD) v[u] = make_double2(vtab[c[u].x], vtab[c[u].y]);
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -342,6 +342,81 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
     if (DOT && act) {
       dacc += dv0 * (s0 - y0);
       if (has1) dacc += dv1 * (s1 - y1);
+    }
+  }
+  if (DOT) {
+    double a1[1] = {dacc};
+    block_sum<1>(a1, lds);
+    __syncthreads();
+    reduce_tail<1, 0>(a1, lds, ctl);
+  }
+}
+
+/* SpMV over the pair dictionary (setup_pairs).  With the values in a table nothing forces a lane to own two ADJACENT rows (that was
+   for 16-byte value loads): lane t owns rows t and t + 256 of the slice, so the gathers of a wave read consecutive entries of x (one
+   512-byte run per instruction when the rows share the diagonal, as the interior of a stencil does) instead of every other one, and
+   a dword brings the codes of 4 slots of a row.  G groups of 4 slots are requested before their gathers start.  Per-row sums run
+   k-ascending with separately rounded multiply and add, as in spmv_sell_kernel: the reference's bits. */
+template <bool NT, bool DOT, int G>
+__global__ __launch_bounds__(PHIP_THREADS) void spmv_pair_kernel(int32_t m, int32_t nslices, const int64_t *__restrict__ pptr, const uint8_t *__restrict__ slen,
+                                                                 const uint32_t *__restrict__ pgrp, const int32_t *__restrict__ poffs, const double *__restrict__ pvals,
+                                                                 int npairs, const double *__restrict__ x, const double *__restrict__ yin, double *__restrict__ yout,
+                                                                 int add, const double *__restrict__ dotv, RedCtl ctl)
+{
+#pragma clang fp contract(off)
+  __shared__ int4   tab[SELL_MAX_OFFS]; /* x: diagonal, z/w: the value's low and high words */
+  __shared__ double lds[4];
+  const int t = threadIdx.x;
+  {
+    const double v = (t < npairs) ? pvals[t] : 0.0;
+    tab[t] = make_int4((t < npairs) ? poffs[t] : 0, 0, __double2loint(v), __double2hiint(v));
+  }
+  __syncthreads();
+  double dacc = 0.0;
+  for (int b = blockIdx.x; b < nslices; b += gridDim.x) {
+    const int  rA = b * SELL_H + t, rB = rA + SELL_H / 2;
+    const bool actA = rA < m, actB = rB < m;
+    const int  lA = actA ? slen[rA] : 0, lB = actB ? slen[rB] : 0;
+    const int  lm = lA > lB ? lA : lB;
+    const uint32_t *cp = pgrp + pptr[b] + t;
+    double yA = 0.0, yB = 0.0;
+    if (add) { if (actA) yA = yin[rA]; if (actB) yB = yin[rB]; }
+    double dvA = 0.0, dvB = 0.0;
+    if (DOT) { if (actA) dvA = dotv[rA]; if (actB) dvB = dotv[rB]; }
+    double sA = yA, sB = yB;
+    for (int g = 0; 4 * g < lm; g += G) {
+      uint32_t cA[G], cB[G];
+#pragma unroll
+      for (int u = 0; u < G; u++) {
+        const bool in = 4 * (g + u) < lm;
+        const uint32_t *q = cp + (size_t)(g + u) * SELL_H;
+        cA[u] = in ? (NT ? __builtin_nontemporal_load(q) : *q) : 0u;
+        cB[u] = in ? (NT ? __builtin_nontemporal_load(q + SELL_H / 2) : q[SELL_H / 2]) : 0u;
+      }
+      double xa[4 * G], xb[4 * G], va[4 * G], vb[4 * G];
+#pragma unroll
+      for (int u = 0; u < G; u++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int  sl = 4 * (g + u) + k;
+          const int4 eA = tab[(cA[u] >> (8 * k)) & 255u], eB = tab[(cB[u] >> (8 * k)) & 255u];
+          xa[4 * u + k] = x[sl < lA ? rA + eA.x : 0];
+          xb[4 * u + k] = x[sl < lB ? rB + eB.x : 0];
+          va[4 * u + k] = __hiloint2double(eA.w, eA.z);
+          vb[4 * u + k] = __hiloint2double(eB.w, eB.z);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4 * G; j++) {
+        if (4 * g + j < lA) sA = sA + va[j] * xa[j];
+        if (4 * g + j < lB) sB = sB + vb[j] * xb[j];
+      }
+    }
+    if (actA) yout[rA] = sA;
+    if (actB) yout[rB] = sB;
+    if (DOT) {
+      if (actA) dacc += dvA * (sA - yA);
+      if (actB) dacc += dvB * (sB - yB);
     }
   }
   if (DOT) {
@@ -548,7 +623,11 @@ static void fill_sell_values(const std::vector<int32_t> &rp, int32_t m, const do
    per entry names both, the two tables sit in LDS, and a nonzero costs 1 byte of HBM traffic instead of 9 (12 in CSR).  The value a
    lane multiplies with is the table's copy of the very double the caller stored (keyed on its bits: -0.0, NaN payloads and
    denormals survive), and the sums run as before, so the result keeps the reference's bits.  phip_mat_update_values rebuilds the
-   pairs; a matrix that stops fitting goes back to streamed values.  PHIP_VALUE_DICT=0 / phip_set_default_value_dict(0) never builds. */
+   pairs; a matrix that stops fitting goes back to streamed values.  PHIP_VALUE_DICT=0 / phip_set_default_value_dict(0) never builds.
+   Measured on MI355X (streamed values -> pair dictionary): 7-point 128^3 25.2 -> 14.1 us (KSPCG 13.6 k -> 16.3 k it/s); 27-point 256^3
+   841 -> 300 us (KSPCG 851 -> 1585 it/s); convection-diffusion 192^3 94 -> 39.5 us.  What bounds it now is no longer HBM (the 27-point
+   case moves 0.72 GB in 300 us) but the rate at which a CU turns codes into gathers: ~1.4 T nonzeros/s, the rate of the bare coalesced
+   gather loop of scripts/micro/gather_rate.hip (1.17 T/s). */
 static int g_vd_mode = -1;
 
 static int build_pairs(const std::vector<uint8_t> &scode, const std::vector<double> &sval, int64_t P, const std::vector<int32_t> &soffs,
@@ -586,8 +665,8 @@ static int build_pairs(const std::vector<uint8_t> &scode, const std::vector<doub
 
 static void free_pairs(phip_mat A)
 {
-  if (A->ctx->device >= 0) { hipFree(A->d_spcode); hipFree(A->d_spoffs); hipFree(A->d_svtab); }
-  A->d_spcode = NULL; A->d_spoffs = NULL; A->d_svtab = NULL; A->vd_built = 0; A->vd_on = 0; A->vd_npairs = 0;
+  if (A->ctx->device >= 0) { hipFree(A->d_spoffs); hipFree(A->d_svtab); hipFree(A->d_pgrp); hipFree(A->d_pptr); }
+  A->d_spoffs = NULL; A->d_svtab = NULL; A->d_pgrp = NULL; A->d_pptr = NULL; A->vd_built = 0; A->vd_on = 0; A->vd_npairs = 0;
 }
 
 /* scode / sval: the SELL-dict arrays on the host; soffs: the diagonal table (its first sell_noffs entries) */
@@ -600,15 +679,37 @@ static int setup_pairs(phip_mat A, const std::vector<uint8_t> &scode, const std:
   std::vector<int32_t> poffs;
   std::vector<double>  pvals;
   if (!build_pairs(scode, sval, A->sell_padded, soffs, pcode, poffs, pvals)) { free_pairs(A); return 0; }
+  /* the grouped copy for spmv_pair_kernel */
+  const int32_t S = A->sell_nslices;
+  std::vector<int64_t> pptr((size_t)S + 1, 0);
+  for (int32_t b = 0; b < S; b++) {
+    const int64_t L = ((*A->h_sptr)[(size_t)b + 1] - (*A->h_sptr)[(size_t)b]) / SELL_H;
+    pptr[(size_t)b + 1] = pptr[(size_t)b] + ((L + 3) / 4) * SELL_H;
+  }
+  std::vector<uint32_t> pgrp((size_t)pptr[(size_t)S] + 4, 0u);
+  for (int32_t b = 0; b < S; b++) {
+    const int64_t  base = (*A->h_sptr)[(size_t)b], L = ((*A->h_sptr)[(size_t)b + 1] - base) / SELL_H;
+    const uint8_t *src = pcode.data() + base;
+    uint32_t      *dst = pgrp.data() + pptr[(size_t)b];
+    for (int64_t sl = 0; sl < L; sl++) {
+      const int      sh = 8 * (int)(sl & 3);
+      uint32_t      *row = dst + (sl >> 2) * SELL_H;
+      const uint8_t *from = src + sl * SELL_H;
+      for (int r = 0; r < SELL_H; r++) row[r] |= (uint32_t)from[r] << sh;
+    }
+  }
   hipStream_t st = A->ctx->stream;
-  if (!A->d_spcode) {
-    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_spcode, pcode.size()));
+  if (!A->d_pgrp) {
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_pgrp, sizeof(uint32_t) * pgrp.size()));
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_pptr, sizeof(int64_t) * pptr.size()));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_spoffs, sizeof(int32_t) * SELL_MAX_OFFS));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_svtab, sizeof(double) * SELL_MAX_OFFS));
   }
   A->vd_npairs = (int32_t)poffs.size();
   poffs.resize(SELL_MAX_OFFS, 0); pvals.resize(SELL_MAX_OFFS, 0.0);
-  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_spcode, pcode.data(), pcode.size(), hipMemcpyHostToDevice, st));
+  A->pgrp_dwords = pptr[(size_t)S];
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_pgrp, pgrp.data(), sizeof(uint32_t) * pgrp.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_pptr, pptr.data(), sizeof(int64_t) * pptr.size(), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_spoffs, poffs.data(), sizeof(int32_t) * SELL_MAX_OFFS, hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_svtab, pvals.data(), sizeof(double) * SELL_MAX_OFFS, hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipStreamSynchronize(st));
@@ -822,19 +923,17 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     static const int dot_grid_env = getenv("PHIP_SPMV_DOT_GRID") ? atoi(getenv("PHIP_SPMV_DOT_GRID")) : 0;
     const int      dot_cap = (dot_grid_env > 0 && dot_grid_env <= PHIP_RED_BLOCKS) ? dot_grid_env : 1024;
     const unsigned grid = DOT ? (unsigned)(A->sell_nslices < dot_cap ? A->sell_nslices : dot_cap) : (unsigned)A->sell_nslices;
-    const bool     vd = A->vd_built && A->vd_on;
-    const bool     nt = (vd ? 1 : 9) * A->sell_padded > PHIP_NT_MATRIX_BYTES;
+    const bool     nt = 9 * A->sell_padded > PHIP_NT_MATRIX_BYTES;
     /* LDS staging of x is correct but measured SLOWER than gathering through L1/L2 (7-point 128^3: 26.9 -> 31.8 us; 27-point 160^3:
-       206 -> 220 us): the gathers are not what bounds this kernel.  Off unless PHIP_SELL_STAGE=1. */
+       206 -> 220 us; with values from the pair dictionary instead of the stream, 27-point 256^3: 327 -> 539 us): the gathers are not
+       what bounds this kernel.  Off unless PHIP_SELL_STAGE=1. */
     static const int stage_env = getenv("PHIP_SELL_STAGE") ? atoi(getenv("PHIP_SELL_STAGE")) : 0;
-    const bool     stage = A->stage_ok && (stage_env != 0 || A->stage_user) && !vd;
+    const bool     stage = A->stage_ok && (stage_env != 0 || A->stage_user);
+    const bool     vd = A->vd_built && A->vd_on && !stage; /* the pair dictionary has a kernel of its own; the x-staging knob belongs to spmv_sell_kernel */
 #define SELL_LAUNCH2(NTv, STv, Uv)                                                                                                                        \
-  hipLaunchKernelGGL((spmv_sell_kernel<NTv, DOT, STv, Uv, false>), dim3(grid), dim3(PHIP_THREADS), (STv) ? sizeof(double) * (size_t)A->stage_lds_doubles : 0, st, A->m, \
+  hipLaunchKernelGGL((spmv_sell_kernel<NTv, DOT, STv, Uv>), dim3(grid), dim3(PHIP_THREADS), (STv) ? sizeof(double) * (size_t)A->stage_lds_doubles : 0, st, A->m, \
                      A->n, A->sell_nslices, A->d_sptr, A->d_slen, A->d_sval, A->d_scode, (STv) ? A->d_sldsoff : A->d_soffs, A->sell_noffs, A->d_scl,      \
                      A->stage_ncl, d_x, d_yin, d_yout, add, d_v, ctl)
-#define SELL_LAUNCH_VD(NTv, Uv)                                                                                                                           \
-  hipLaunchKernelGGL((spmv_sell_kernel<NTv, DOT, false, Uv, true>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_sptr, A->d_slen,   \
-                     A->d_svtab, A->d_spcode, A->d_spoffs, A->vd_npairs, A->d_scl, A->stage_ncl, d_x, d_yin, d_yout, add, d_v, ctl)
     /* slots requested per lane before the gathers start: 8 for long rows (27-point 192^3: 361.9 -> 349.7 us), 4 otherwise (rows of 7
        never fill a batch of 8: 27.1 -> 36.1 us); PHIP_SELL_UNROLL=4|8 overrides */
     static const int unroll_env = getenv("PHIP_SELL_UNROLL") ? atoi(getenv("PHIP_SELL_UNROLL")) : 0;
@@ -843,16 +942,24 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
        x[r] from the row's own diagonal gather instead of a second load (256^3: 903 -> 967 us, the per-slot test costs more) */
     const int        unroll = unroll_env ? unroll_env : ((A->sell_maxlen >= 16 && !DOT) ? 8 : 4);
 #define SELL_LAUNCH(NTv, STv) do { if (unroll == 8) SELL_LAUNCH2(NTv, STv, 8); else SELL_LAUNCH2(NTv, STv, 4); } while (0)
+    /* groups of 4 slots requested per lane before their gathers start: 2 for short rows, 1 for long ones (7-point 128^3 inside KSPCG
+       16.19 k -> 16.34 k it/s with 2; 27-point 256^3 SpMV 327 -> 300 us with 1); PHIP_PAIR_GROUPS=1|2 overrides */
+    static const int pair_g_env = getenv("PHIP_PAIR_GROUPS") ? atoi(getenv("PHIP_PAIR_GROUPS")) : 0;
     if (vd) {
-      if (nt) { if (unroll == 8) SELL_LAUNCH_VD(true, 8); else SELL_LAUNCH_VD(true, 4); }
-      else { if (unroll == 8) SELL_LAUNCH_VD(false, 8); else SELL_LAUNCH_VD(false, 4); }
+      const bool pnt = 4 * A->pgrp_dwords > PHIP_NT_MATRIX_BYTES;
+      const int  G = pair_g_env ? pair_g_env : (A->sell_maxlen >= 16 ? 1 : 2);
+#define PAIR_LAUNCH(NTv, Gv)                                                                                                                              \
+  hipLaunchKernelGGL((spmv_pair_kernel<NTv, DOT, Gv>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->m, A->sell_nslices, A->d_pptr, A->d_slen, A->d_pgrp, A->d_spoffs, \
+                     A->d_svtab, A->vd_npairs, d_x, d_yin, d_yout, add, d_v, ctl)
+      if (pnt) { if (G == 2) PAIR_LAUNCH(true, 2); else PAIR_LAUNCH(true, 1); }
+      else { if (G == 2) PAIR_LAUNCH(false, 2); else PAIR_LAUNCH(false, 1); }
+#undef PAIR_LAUNCH
     }
     else if (nt && stage) SELL_LAUNCH(true, true);
     else if (nt) SELL_LAUNCH(true, false);
     else if (stage) SELL_LAUNCH(false, true);
     else SELL_LAUNCH(false, false);
 #undef SELL_LAUNCH2
-#undef SELL_LAUNCH_VD
 #undef SELL_LAUNCH
   } else {
     static const int dot_grid_env = getenv("PHIP_SPMV_DOT_GRID") ? atoi(getenv("PHIP_SPMV_DOT_GRID")) : 0;

@@ -334,8 +334,11 @@ def test_value_pair_dictionary(ctx, orc):
         ctx.check(L.phip_mat_set_value_dict(A, 0))
         assert info(A)[1] == 0
         off = products(A, m, x, v, y0)
-        for a, b in zip(on, off):
-            np.testing.assert_array_equal(a, b)
+        for k, (a, b) in enumerate(zip(on, off)):
+            if k == 3:   # the fused dot: the two kernels map rows to lanes differently, so its partial sums are grouped differently
+                assert abs(a[0] - b[0]) <= 1e-13 * np.abs(v * on[2]).sum()
+            else:
+                np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(on[0], orc.matmult(ai, aj, aa, x))
         ctx.check(L.phip_mat_set_value_dict(A, 1))
         # values that no longer fit: the matrix goes back to streamed values, and returns to the dictionary when they fit again
