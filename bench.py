@@ -144,11 +144,19 @@ def main():
     # (1 B per entry when the matrix has <= 256 distinct (diagonal, value) pairs: the pair dictionary)
     vdb_, vdu_, vdn_ = C.c_int(), C.c_int(), C.c_int32()
     L.phip_mat_value_dict_info(hA, C.byref(vdb_), C.byref(vdu_), C.byref(vdn_))
+    # (a 32-bit set of pairs per ROW when there are <= 32 of them: the diagonal-mask layout)
+    dmb_, dmu_, dmn_ = C.c_int(), C.c_int(), C.c_int32()
+    L.phip_mat_diag_mask_info(hA, C.byref(dmb_), C.byref(dmu_), C.byref(dmn_))
     entry_bytes = 1 if vdu_.value else 9
-    layout_bytes = (entry_bytes * pad_.value + 17 * m + 8 * ((m + 511) // 512)) if f_.value == 2 else (12 * nzA + 20 * m + 4)
-    kernel_name = ("spmv_pair_kernel" if vdu_.value else "spmv_sell_kernel") if f_.value == 2 else "spmv_rowblock_kernel"
-    layout_name = ("SELL-dict, pair dictionary of %d (diagonal, value) pairs (1 B/nz)" % vdn_.value if vdu_.value else "SELL-dict (9 B/nz)") if f_.value == 2 \
-        else "CSR row blocks (12 B/nz)"
+    if f_.value != 2:
+        layout_bytes, kernel_name, layout_name = 12 * nzA + 20 * m + 4, "spmv_rowblock_kernel", "CSR row blocks (12 B/nz)"
+    elif dmu_.value:
+        layout_bytes, kernel_name = 20 * m, "spmv_dmask_kernel"
+        layout_name = "diagonal masks: %d (diagonal, value) pairs, a 32-bit set of them per row (4 B/row)" % dmn_.value
+    else:
+        layout_bytes = entry_bytes * pad_.value + 17 * m + 8 * ((m + 511) // 512)
+        kernel_name = "spmv_pair_kernel" if vdu_.value else "spmv_sell_kernel"
+        layout_name = "SELL-dict, pair dictionary of %d (diagonal, value) pairs (1 B/nz)" % vdn_.value if vdu_.value else "SELL-dict (9 B/nz)"
     spmv_bytes = 12 * nzA + 20 * m + 4
     spmv_add_bytes = (12 * nzB + 28 * mB) if nzB else 0
     iter_bytes = spmv_bytes + spmv_add_bytes + 136 * m
@@ -226,7 +234,7 @@ def main():
                          "bytes_per_launch": spmv_bytes, "avg_launch_us": round(b2b_ms * 1e3, 2),
                          "layout": layout_name, "layout_bytes_per_launch": layout_bytes,
                          "layout_GBps": round(layout_bytes / (b2b_ms * 1e-3) / 1e9, 1), "layout_frac": round(layout_bytes / (b2b_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "note": "achieved = ALGORITHMIC CSR bytes (12 nz + 20 m + 4, SURVEY.md 8d) / launch time; the SELL-dict layout streams fewer bytes (layout_*: one byte per entry names diagonal and value when the matrix has <= 256 distinct pairs, lossless; PHIP_VALUE_DICT=0 streams the values, 9 B/nz), and the 128^3 working set fits the 256 MiB Infinity Cache, so achieved can exceed the HBM peak",
+                         "note": "achieved = ALGORITHMIC CSR bytes (12 nz + 20 m + 4, SURVEY.md 8d) / launch time; the stencil layouts stream fewer bytes (layout_*: SELL-dict 9 B/nz; 1 B/nz when the matrix has <= 256 distinct (diagonal, value) pairs; 4 B/row when <= 32; all lossless, same bits; PHIP_VALUE_DICT=0 streams the values), and the 128^3 working set fits the 256 MiB Infinity Cache, so achieved can exceed the HBM peak",
                          "how": "%d launches back to back between two hipEvents on the library's compute stream, best of 3 (rocprofv3 average of the same kernel: profiles/)" % reps,
                          "avg_launch_us_inside_cg_event_pairs": round(spmv_ms * 1e3, 2), "achievable_peak_note": "6.29 TB/s measured float4 copy (MI355X_MICROARCH.md)"},
             "final_rnorm": res["rnorm"], "setup_s": round(setup_s, 2),

@@ -131,6 +131,16 @@ int phip_mat_format_info(phip_mat A, int *format, int32_t *ndiagonals, int64_t *
 int phip_set_default_value_dict(int mode);
 int phip_mat_set_value_dict(phip_mat A, int on);
 int phip_mat_value_dict_info(phip_mat A, int *built, int *in_use, int32_t *npairs);
+/* Diagonal-mask layout, on top of the pair dictionary when it has <= 32 pairs and every row meets its pairs in ascending diagonal
+ * order (sorted rows without repeated columns): the pairs are sorted by diagonal and a row is a 32-bit set of the pairs it holds --
+ * 4 bytes per ROW.  The kernel loops over the pairs; two adjacent rows of a lane read x with one 16-byte load.  Same products, same
+ * k-ascending sums: same bits.  phip_set_default_diag_mask(0) / PHIP_DIAG_MASK=0: never build; 1 (default): build, and use it for
+ * the plain products and, from 40 M nonzeros on, for the products with a fused dot (which then take a second, one-workgroup launch
+ * that sums one partial per slice; smaller matrices keep the single-launch pair-code kernel there); 2: for every product.
+ * phip_mat_set_diag_mask switches a built layout off (back to the pair codes) and on. */
+int phip_set_default_diag_mask(int mode);
+int phip_mat_set_diag_mask(phip_mat A, int on);
+int phip_mat_diag_mask_info(phip_mat A, int *built, int *in_use, int32_t *npairs);
 /* tuning: SELL-dict kernel gathers x from LDS-staged contiguous segments (one per cluster of nearby diagonals) instead of through
  * L1/L2; same bits; measured slower on MI355X for 7- and 27-point stencils, hence off by default */
 int phip_mat_set_x_staging(phip_mat A, int on);

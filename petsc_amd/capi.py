@@ -50,6 +50,9 @@ SIGNATURES = [
     ("phip_set_default_value_dict", C.c_int, [C.c_int]),
     ("phip_mat_set_value_dict", C.c_int, [_vp, C.c_int]),
     ("phip_mat_value_dict_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pI]),
+    ("phip_set_default_diag_mask", C.c_int, [C.c_int]),
+    ("phip_mat_set_diag_mask", C.c_int, [_vp, C.c_int]),
+    ("phip_mat_diag_mask_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pI]),
     ("phip_set_default_hot_columns", C.c_int, [C.c_int]),
     ("phip_mat_set_hot_columns", C.c_int, [_vp, C.c_int]),
     ("phip_mat_hot_columns_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pD, _pD]),

@@ -86,6 +86,13 @@ struct phip_mat_s {
   int64_t   pgrp_dwords;
   int32_t *d_spoffs;  /* [256] diagonal of each pair */
   double  *d_svtab;   /* [256] value of each pair */
+  /* diagonal-mask layout (setup_dmask): <= 32 pairs sorted by diagonal, one presence bit per pair and row */
+  int       dm_built, dm_on;
+  int32_t   dm_npairs;
+  uint32_t *d_rmask;  /* [S * 512] bit q of rmask[r]: row r holds pair q */
+  double   *d_dotpart; /* [S] the fused dot's partial sum of each slice (full-grid variant, see launch_spmv_t) */
+  int32_t  *d_dmoffs; /* [32] */
+  double   *d_dmvals; /* [32] */
   std::vector<uint8_t> *h_scode; /* host copies of scode and soffs: phip_mat_update_values rebuilds the pairs from them */
   std::vector<int32_t> *h_soffs;
   /* operator of y = A^T x: a second matrix holding A^T row by row, built on request (phip_mat_transpose_setup) */
@@ -427,6 +434,116 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_pair_kernel(int32_t m, int3
   }
 }
 
+/* SpMV in the diagonal-mask layout (setup_dmask).  The pair kernel above runs at the rate of the texture addresser: every gather is a
+   separate 8-byte load per lane, and a CU accepts 4 lane addresses per clock whatever their width (measured: TA busy for the whole
+   kernel, 1.9 T lane loads/s of a 2.2 T/s ceiling, VALU 48 % busy; profiles/r01_pmc_pair_kernel_27pt_192.json).  When the pairs are
+   few (<= 32) the matrix can be held in DIAGONAL space instead of slot space: the pairs are sorted by diagonal, a row is a 32-bit set of
+   the pairs it holds, and the loop runs over the pairs, not over the row's slots.  Then the diagonal is the same for every row of a
+   wave, so a lane that owns two ADJACENT rows reads x[r + d] and x[r + 1 + d] with ONE 16-byte load: half the lane addresses per
+   nonzero, no code stream, no LDS table (diagonal and value of the current pair live in scalar registers).  Ascending diagonal is
+   ascending column, so a row still adds its products k-ascending with separately rounded multiply and add: the reference's bits.
+   Pairs no row of the wave holds are skipped; a wave whose 16-byte loads could leave x (first and last rows of the matrix, far
+   diagonals) takes the entries one by one. */
+typedef double phip_v2d_u __attribute__((ext_vector_type(2), aligned(8)));
+
+template <bool DOT, int U>
+__global__ __launch_bounds__(PHIP_THREADS) void spmv_dmask_kernel(int32_t m, int32_t n, int32_t nslices, const uint32_t *__restrict__ rmask,
+                                                                  const int32_t *__restrict__ poffs, const double *__restrict__ pvals,
+                                                                  const double *__restrict__ x, const double *__restrict__ yin, double *__restrict__ yout,
+                                                                  int add, const double *__restrict__ dotv, double *__restrict__ wgpart, RedCtl ctl)
+{
+#pragma clang fp contract(off)
+  __shared__ double lds[4];
+  const int t = threadIdx.x;
+  double    dacc = 0.0;
+  for (int b = blockIdx.x; b < nslices; b += gridDim.x) {
+    const int   r0 = b * SELL_H + 2 * t;
+    const bool  actA = r0 < m, actB = r0 + 1 < m;
+    const uint2 mk = reinterpret_cast<const uint2 *>(rmask)[(size_t)b * (SELL_H / 2) + t];
+    const uint32_t mA = mk.x, mB = mk.y;
+    double yA = 0.0, yB = 0.0;
+    if (add) { if (actA) yA = yin[r0]; if (actB) yB = yin[r0 + 1]; }
+    double dvA = 0.0, dvB = 0.0;
+    if (DOT) { if (actA) dvA = dotv[r0]; if (actB) dvB = dotv[r0 + 1]; }
+    double sA = yA, sB = yB;
+    /* the pairs some row of this wave holds */
+    uint32_t um = mA | mB;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) um |= (uint32_t)__shfl_xor((int)um, o, 64);
+    uint32_t  rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)um);
+    const int w0 = b * SELL_H + (t & ~63) * 2; /* first of the 128 rows of this wave */
+    while (rem) {
+      int pp[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (rem) { pp[u] = __builtin_ctz(rem); rem &= rem - 1; }
+        else pp[u] = -1;
+      }
+      double xa[U], xb[U], vv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        xa[u] = xb[u] = vv[u] = 0.0;
+        if (pp[u] >= 0) {
+          const int d = poffs[pp[u]];
+          vv[u] = pvals[pp[u]];
+          if (w0 + d >= 0 && (int64_t)w0 + 127 + d < (int64_t)n) { /* the whole wave stays inside x */
+            const phip_v2d_u q = *reinterpret_cast<const phip_v2d_u *>(x + (r0 + d));
+            xa[u] = q.x; xb[u] = q.y;
+          } else {
+            if ((mA >> pp[u]) & 1u) xa[u] = x[r0 + d];
+            if ((mB >> pp[u]) & 1u) xb[u] = x[r0 + 1 + d];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (pp[u] >= 0) {
+          if ((mA >> pp[u]) & 1u) sA = sA + vv[u] * xa[u];
+          if ((mB >> pp[u]) & 1u) sB = sB + vv[u] * xb[u];
+        }
+      }
+    }
+    if (actB) *reinterpret_cast<double2 *>(yout + r0) = make_double2(sA, sB);
+    else if (actA) yout[r0] = sA;
+    if (DOT) {
+      if (actA) dacc += dvA * (sA - yA);
+      if (actB) dacc += dvB * (sB - yB);
+    }
+  }
+  if (DOT) {
+    double a1[1] = {dacc};
+    block_sum<1>(a1, lds);
+    if (wgpart) { /* one workgroup per slice: the partial waits for dot_partials_kernel */
+      if (t == 0) wgpart[blockIdx.x] = a1[0];
+      return;
+    }
+    __syncthreads();
+    reduce_tail<1, 0>(a1, lds, ctl);
+  }
+}
+
+/* second half of the fused dot when the product ran one workgroup per slice: nb partials, summed in a fixed order (thread t adds
+   the entries t, t + 256, ...; then the block tree) and published as reduce_tail publishes */
+__global__ __launch_bounds__(PHIP_THREADS) void dot_partials_kernel(const double *__restrict__ part, int nb, RedCtl c)
+{
+  __shared__ double lds[4];
+  const int t = threadIdx.x;
+  double    a1[1] = {0.0};
+  int       i = t;
+  for (; i + 3 * PHIP_THREADS < nb; i += 4 * PHIP_THREADS) { /* four loads in flight, added in index order */
+    const double p0 = part[i], p1 = part[i + PHIP_THREADS], p2 = part[i + 2 * PHIP_THREADS], p3 = part[i + 3 * PHIP_THREADS];
+    a1[0] += p0; a1[0] += p1; a1[0] += p2; a1[0] += p3;
+  }
+  for (; i < nb; i += PHIP_THREADS) a1[0] += part[i];
+  block_sum<1>(a1, lds);
+  if (t == 0) {
+    const double r = c.accumulate ? c.d_out[c.kofs] + a1[0] : a1[0];
+    c.d_out[c.kofs] = r;
+    if (c.h_ll && c.kofs < c.npub) publish_ll(c.h_ll, c.kofs, r, c.seq);
+  }
+  if (c.h_ll && t < c.kofs && t < c.npub) publish_ll(c.h_ll, t, c.d_out[t], c.seq);
+}
+
 __global__ void getdiag_kernel(int32_t m, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx, int32_t R,
                                const int32_t *__restrict__ col, const double *__restrict__ val, double *__restrict__ v, int cprow)
 {
@@ -663,10 +780,68 @@ static int build_pairs(const std::vector<uint8_t> &scode, const std::vector<doub
   return 1;
 }
 
+static void free_dmask(phip_mat A);
 static void free_pairs(phip_mat A)
 {
+  free_dmask(A);
   if (A->ctx->device >= 0) { hipFree(A->d_spoffs); hipFree(A->d_svtab); hipFree(A->d_pgrp); hipFree(A->d_pptr); }
   A->d_spoffs = NULL; A->d_svtab = NULL; A->d_pgrp = NULL; A->d_pptr = NULL; A->vd_built = 0; A->vd_on = 0; A->vd_npairs = 0;
+}
+
+static void free_dmask(phip_mat A)
+{
+  if (A->ctx->device >= 0) { hipFree(A->d_rmask); hipFree(A->d_dmoffs); hipFree(A->d_dmvals); hipFree(A->d_dotpart); }
+  A->d_rmask = NULL; A->d_dmoffs = NULL; A->d_dmvals = NULL; A->d_dotpart = NULL; A->dm_built = 0; A->dm_on = 0; A->dm_npairs = 0;
+}
+
+/* diagonal-mask layout out of the pair codes (slot-major bytes, laid out like scode).  Not built when there are more than 32 pairs or
+   when some row does not meet its pairs in strictly ascending diagonal order (unsorted or repeated columns): such a row's k-ascending
+   sum is not the ascending-diagonal sum. */
+#define DMASK_MAX_PAIRS 32
+static int g_dm_mode = -1;
+static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std::vector<int32_t> &poffs, const std::vector<double> &pvals, int npairs)
+{
+  const int was_on = A->dm_built ? A->dm_on : 1;
+  if (g_dm_mode < 0) g_dm_mode = getenv("PHIP_DIAG_MASK") ? atoi(getenv("PHIP_DIAG_MASK")) : 1;
+  if (A->ctx->device < 0 || g_dm_mode == 0 || npairs > DMASK_MAX_PAIRS || npairs < 1) { free_dmask(A); return 0; }
+  int order[DMASK_MAX_PAIRS], rank[DMASK_MAX_PAIRS];
+  for (int q = 0; q < npairs; q++) order[q] = q;
+  std::stable_sort(order, order + npairs, [&](int a, int b) { return poffs[(size_t)a] < poffs[(size_t)b]; });
+  for (int q = 0; q < npairs; q++) rank[order[q]] = q;
+  const int32_t         S = A->sell_nslices;
+  std::vector<uint32_t> rmask((size_t)S * SELL_H + 2, 0u);
+  const std::vector<int32_t> &rp = *A->h_rowptr;
+  for (int32_t r = 0; r < A->m; r++) {
+    const int32_t b = r / SELL_H;
+    const int64_t pos0 = (*A->h_sptr)[(size_t)b] + (r - b * SELL_H);
+    const int     len = rp[(size_t)r + 1] - rp[(size_t)r];
+    int           last = -1, lastoff = 0;
+    uint32_t      mk = 0;
+    for (int sl = 0; sl < len; sl++) {
+      const int q = rank[pcode[(size_t)(pos0 + (int64_t)sl * SELL_H)]];
+      const int off = poffs[(size_t)order[q]];
+      if (q <= last || (last >= 0 && off <= lastoff)) { free_dmask(A); return 0; }
+      last = q; lastoff = off;
+      mk |= 1u << q;
+    }
+    rmask[(size_t)r] = mk;
+  }
+  int32_t offs[DMASK_MAX_PAIRS] = {0};
+  double  vals[DMASK_MAX_PAIRS] = {0.0};
+  for (int q = 0; q < npairs; q++) { offs[q] = poffs[(size_t)order[q]]; vals[q] = pvals[(size_t)order[q]]; }
+  hipStream_t st = A->ctx->stream;
+  if (!A->d_rmask) {
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rmask, sizeof(uint32_t) * rmask.size()));
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dmoffs, sizeof(offs)));
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dmvals, sizeof(vals)));
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dotpart, sizeof(double) * ((size_t)S + 1)));
+  }
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_rmask, rmask.data(), sizeof(uint32_t) * rmask.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmoffs, offs, sizeof(offs), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmvals, vals, sizeof(vals), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipStreamSynchronize(st));
+  A->dm_built = 1; A->dm_on = was_on; A->dm_npairs = npairs;
+  return 0;
 }
 
 /* scode / sval: the SELL-dict arrays on the host; soffs: the diagonal table (its first sell_noffs entries) */
@@ -706,6 +881,10 @@ static int setup_pairs(phip_mat A, const std::vector<uint8_t> &scode, const std:
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_svtab, sizeof(double) * SELL_MAX_OFFS));
   }
   A->vd_npairs = (int32_t)poffs.size();
+  {
+    int rc = setup_dmask(A, pcode, poffs, pvals, A->vd_npairs);
+    if (rc) return rc;
+  }
   poffs.resize(SELL_MAX_OFFS, 0); pvals.resize(SELL_MAX_OFFS, 0.0);
   A->pgrp_dwords = pptr[(size_t)S];
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_pgrp, pgrp.data(), sizeof(uint32_t) * pgrp.size(), hipMemcpyHostToDevice, st));
@@ -945,7 +1124,29 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     /* groups of 4 slots requested per lane before their gathers start: 2 for short rows, 1 for long ones (7-point 128^3 inside KSPCG
        16.19 k -> 16.34 k it/s with 2; 27-point 256^3 SpMV 327 -> 300 us with 1); PHIP_PAIR_GROUPS=1|2 overrides */
     static const int pair_g_env = getenv("PHIP_PAIR_GROUPS") ? atoi(getenv("PHIP_PAIR_GROUPS")) : 0;
-    if (vd) {
+    /* Diagonal masks: 7-point 128^3 14.1 -> 13.1 us, 27-point 256^3 300 -> 226 us against the pair codes.  With the fused dot on a
+       capped grid a workgroup walks several slices one after the other, each starting with its serial prologue (masks, wave-wide
+       OR), and loses what the wider loads give (7-point 128^3 inside KSPCG 20.8 -> 23.2 us at 1024 workgroups; 27-point 192^3: 136 us
+       at 4096 workgroups against 90 us for the plain product).  So the fused dot runs like the plain product, one workgroup per
+       slice, leaves one partial per slice, and a one-workgroup kernel right behind it sums and publishes them
+       (dot_partials_kernel): deterministic, and the product keeps its speed.  The second launch costs ~2 us, so small matrices keep
+       the single-launch pair-code kernel for the fused dot.  KSPCG it/s, masks against pair codes: 7-point 128^3 15.4 k / 16.2 k,
+       192^3 5671 / 5602, 256^3 2294 / 2268; 27-point 128^3 11.90 k / 11.71 k, 192^3 4188 / 3707, 256^3 1741 / 1579 -- the masks from
+       40 M nonzeros on.  PHIP_DMASK_DOT=0|1 overrides. */
+    static const int dm_u_env = getenv("PHIP_DMASK_UNROLL") ? atoi(getenv("PHIP_DMASK_UNROLL")) : 0;
+    static const int dm_dot_env = getenv("PHIP_DMASK_DOT") ? atoi(getenv("PHIP_DMASK_DOT")) : -1;
+    if (vd && A->dm_built && A->dm_on && (!DOT || g_dm_mode == 2 || (dm_dot_env >= 0 ? dm_dot_env != 0 : A->nnz >= 40000000))) {
+      const unsigned dgrid = (unsigned)A->sell_nslices;
+      double        *part = DOT ? A->d_dotpart : NULL;
+      if (dm_u_env == 8)
+        hipLaunchKernelGGL((spmv_dmask_kernel<DOT, 8>), dim3(dgrid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_rmask, A->d_dmoffs, A->d_dmvals, d_x,
+                           d_yin, d_yout, add, d_v, part, ctl);
+      else
+        hipLaunchKernelGGL((spmv_dmask_kernel<DOT, 4>), dim3(dgrid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_rmask, A->d_dmoffs, A->d_dmvals, d_x,
+                           d_yin, d_yout, add, d_v, part, ctl);
+      if (DOT) hipLaunchKernelGGL(dot_partials_kernel, dim3(1), dim3(PHIP_THREADS), 0, st, A->d_dotpart, A->sell_nslices, ctl);
+    }
+    else if (vd) {
       const bool pnt = 4 * A->pgrp_dwords > PHIP_NT_MATRIX_BYTES;
       const int  G = pair_g_env ? pair_g_env : (A->sell_maxlen >= 16 ? 1 : 2);
 #define PAIR_LAUNCH(NTv, Gv)                                                                                                                              \
@@ -1235,6 +1436,32 @@ extern "C" int phip_mat_value_dict_info(phip_mat A, int *built, int *in_use, int
   if (built) *built = A->vd_built;
   if (in_use) *in_use = A->vd_built && A->vd_on && A->sell_on;
   if (npairs) *npairs = A->vd_built ? A->vd_npairs : 0;
+  return 0;
+}
+
+/* diagonal-mask layout (setup_dmask): on = 0 falls back to the pair codes, 1 uses the masks built at upload (error if none) */
+extern "C" int phip_set_default_diag_mask(int mode)
+{
+  PHIP_REQUIRE(mode >= 0 && mode <= 2, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_default_diag_mask: %d (0 never, 1 when the matrix allows, 2 also for the fused dot of small matrices)", mode);
+  g_dm_mode = mode;
+  return 0;
+}
+
+extern "C" int phip_mat_set_diag_mask(phip_mat A, int on)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_set_diag_mask: null matrix");
+  PHIP_REQUIRE(!on || A->dm_built, PHIP_ERR_SUP, "phip_mat_set_diag_mask: no diagonal-mask layout was built for this matrix");
+  A->dm_on = on ? 1 : 0;
+  if (A->T && A->T->dm_built) A->T->dm_on = A->dm_on;
+  return 0;
+}
+
+extern "C" int phip_mat_diag_mask_info(phip_mat A, int *built, int *in_use, int32_t *npairs)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_diag_mask_info: null matrix");
+  if (built) *built = A->dm_built;
+  if (in_use) *in_use = A->dm_built && A->dm_on && A->vd_built && A->vd_on && A->sell_on;
+  if (npairs) *npairs = A->dm_built ? A->dm_npairs : 0;
   return 0;
 }
 

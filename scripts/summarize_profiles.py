@@ -28,7 +28,7 @@ for nm, pat in (("FETCH_SIZE", "gpurun_out/prof_fetch/*/*_counter_collection.csv
         out.setdefault(k, {})[nm + "_KB_avg"] = sum(v) / len(v)
         out[k][nm + "_launches"] = len(v)
 json.dump(out, open("profiles/%s_bench_%s_pmc_hbm.json" % (tag, workload), "w"), indent=1, sort_keys=True)
-spmv = [k for k in out if "spmv_sell" in k or "spmv_rowblock" in k or "spmv_pair" in k]
+spmv = [k for k in out if "spmv_sell" in k or "spmv_rowblock" in k or "spmv_pair" in k or "spmv_dmask" in k]
 spmv.sort(key=lambda k: -out[k].get("FETCH_SIZE_launches", 0))
 k = spmv[0]
 traffic = int(2 * out[k]["FETCH_SIZE_KB_avg"] * 1024 + out[k]["WRITE_SIZE_KB_avg"] * 1024)

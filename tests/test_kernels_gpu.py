@@ -318,7 +318,8 @@ def test_value_pair_dictionary(ctx, orc):
             ctx.free(pz)
         return out
 
-    cases = [G.laplace3d_7pt(24), G.box3d_27pt(17), G.convdiff3d_7pt(19, 13, 11), G.laplace2d_5pt(57, 31), G.laplace2d_5pt(1, 700)]
+    cases = [G.laplace3d_7pt(24), G.box3d_27pt(17), G.convdiff3d_7pt(19, 13, 11), G.laplace2d_5pt(57, 31), G.laplace2d_5pt(1, 700),
+             G.laplace2d_5pt(700, 1), G.laplace3d_7pt(3, 5, 300)]
     for ci, (ai, aj, aa) in enumerate(cases):
         m = len(ai) - 1
         aa = aa.copy()
@@ -330,17 +331,37 @@ def test_value_pair_dictionary(ctx, orc):
         assert (built, used) == (1, 1) and 1 <= npairs <= 256
         pi, pj, pa = (ai.ctypes.data_as(C.POINTER(C.c_int32)), aj.ctypes.data_as(C.POINTER(C.c_int32)), aa.ctypes.data_as(C.POINTER(C.c_double)))
         ctx.check(L.phip_mat_transpose_setup(A, pi, pj, pa))
+        # three kernels over the same matrix: diagonal masks (<= 32 pairs), pair codes, streamed values
+        db, du, dn = C.c_int(), C.c_int(), C.c_int32()
+        ctx.check(L.phip_mat_diag_mask_info(A, C.byref(db), C.byref(du), C.byref(dn)))
+        assert (db.value, du.value) == (1, 1) and dn.value == npairs <= 32
         on = products(A, m, x, v, y0)
-        ctx.check(L.phip_mat_set_value_dict(A, 0))
-        assert info(A)[1] == 0
-        off = products(A, m, x, v, y0)
-        for k, (a, b) in enumerate(zip(on, off)):
-            if k == 3:   # the fused dot: the two kernels map rows to lanes differently, so its partial sums are grouped differently
+        ctx.check(L.phip_set_default_diag_mask(2))   # the fused dot through the masks too (default: only from 40 M nonzeros on)
+        try:
+            on2 = products(A, m, x, v, y0)
+        finally:
+            ctx.check(L.phip_set_default_diag_mask(1))
+        for k, (a, b) in enumerate(zip(on, on2)):
+            if k == 3:
                 assert abs(a[0] - b[0]) <= 1e-13 * np.abs(v * on[2]).sum()
             else:
                 np.testing.assert_array_equal(a, b)
+        ctx.check(L.phip_mat_set_diag_mask(A, 0))
+        ctx.check(L.phip_mat_diag_mask_info(A, C.byref(db), C.byref(du), C.byref(dn)))
+        assert (db.value, du.value) == (1, 0)
+        pairs = products(A, m, x, v, y0)
+        ctx.check(L.phip_mat_set_value_dict(A, 0))
+        assert info(A)[1] == 0
+        off = products(A, m, x, v, y0)
+        for other in (pairs, off):
+            for k, (a, b) in enumerate(zip(on, other)):
+                if k == 3:   # the fused dot: the kernels map rows to lanes differently, so its partial sums are grouped differently
+                    assert abs(a[0] - b[0]) <= 1e-13 * np.abs(v * on[2]).sum()
+                else:
+                    np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(on[0], orc.matmult(ai, aj, aa, x))
         ctx.check(L.phip_mat_set_value_dict(A, 1))
+        ctx.check(L.phip_mat_set_diag_mask(A, 1))
         # values that no longer fit: the matrix goes back to streamed values, and returns to the dictionary when they fit again
         many = aa * rng.uniform(0.5, 1.5, len(aa))
         ctx.check(L.phip_mat_update_values(A, many.ctypes.data_as(C.POINTER(C.c_double))))
@@ -348,13 +369,29 @@ def test_value_pair_dictionary(ctx, orc):
             assert info(A)[:2] == (0, 0)
             assert L.phip_mat_set_value_dict(A, 1) != 0
         np.testing.assert_array_equal(products(A, m, x, v, y0)[0], orc.matmult(ai, aj, many, x))
-        few = np.round(many * 2.0) / 2.0 + 0.25
+        few = np.round(many / 2.0) * 2.0 + 0.25
         ctx.check(L.phip_mat_update_values(A, few.ctypes.data_as(C.POINTER(C.c_double))))
         assert info(A)[:2] == (1, 1)
         got = products(A, m, x, v, y0)
         np.testing.assert_array_equal(got[0], orc.matmult(ai, aj, few, x))
         np.testing.assert_array_equal(got[4], orc.matmulttranspose(ai, aj, few, m, v))
         ctx.check(L.phip_mat_destroy(A))
+    # more than 32 pairs: pair codes, no masks
+    ai, aj, aa = G.laplace3d_7pt(24)
+    aa = aa.copy()
+    aa[::7] = np.round(rng.uniform(1, 12, len(aa[::7])))       # a dozen more values on top of the stencil's
+    m = len(ai) - 1
+    A = ctx.mat_create(m, m, ai, aj, aa)
+    db, du, dn = C.c_int(), C.c_int(), C.c_int32()
+    ctx.check(L.phip_mat_diag_mask_info(A, C.byref(db), C.byref(du), C.byref(dn)))
+    assert info(A)[:2] == (1, 1) and 32 < info(A)[2] <= 256 and (db.value, du.value) == (0, 0)
+    assert L.phip_mat_set_diag_mask(A, 1) != 0
+    x = G.random_vector(m)
+    dx, dy = ctx.to_device(x), ctx.to_device(np.zeros(m))
+    ctx.check(L.phip_mat_mult(A, dx, dy))
+    np.testing.assert_array_equal(ctx.to_host(dy, m), orc.matmult(ai, aj, aa, x))
+    ctx.free(dx); ctx.free(dy)
+    ctx.check(L.phip_mat_destroy(A))
     # never built when switched off, nor for matrices outside the SELL-dict layout
     ctx.check(L.phip_set_default_value_dict(0))
     try:
