@@ -530,9 +530,12 @@ __global__ __launch_bounds__(PHIP_THREADS) void dot_partials_kernel(const double
   const int t = threadIdx.x;
   double    a1[1] = {0.0};
   int       i = t;
-  for (; i + 3 * PHIP_THREADS < nb; i += 4 * PHIP_THREADS) { /* four loads in flight, added in index order */
-    const double p0 = part[i], p1 = part[i + PHIP_THREADS], p2 = part[i + 2 * PHIP_THREADS], p3 = part[i + 3 * PHIP_THREADS];
-    a1[0] += p0; a1[0] += p1; a1[0] += p2; a1[0] += p3;
+  for (; i + 15 * PHIP_THREADS < nb; i += 16 * PHIP_THREADS) { /* sixteen loads in flight, added in index order */
+    double p[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) p[u] = part[i + u * PHIP_THREADS];
+#pragma unroll
+    for (int u = 0; u < 16; u++) a1[0] += p[u];
   }
   for (; i < nb; i += PHIP_THREADS) a1[0] += part[i];
   block_sum<1>(a1, lds);
