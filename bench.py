@@ -191,6 +191,32 @@ def main():
     dsync()
     matmult_ms = min(fmt_probe.time_region(lambda: A.mult(x, b), reps) for _ in range(3))
 
+    # the two vector launches of a KSPCG iteration, back to back like the SpMV above (rank 0's figures are reported): the batch
+    # VecAXPY(X,a,P) + VecAXPY(R,-a,W) + PCApply_Jacobi(R,Z) with its three fused sums (cg.c:222-229: 5 vectors read, 3 written), and
+    # VecAYPX(P,b,Z) (cg.c:252: 2 read, 1 written)
+    from petsc_amd.capi import Ticket
+    vecs = [fmt_probe.to_device(np.linspace(0.1, 1.0, m) * (k + 1)) for k in range(7)]
+    vx, vp, vr, vw, vd, vz, _ = vecs
+    tk = Ticket()
+
+    def cg_batch():
+        L.phip_vec_axpy(comm.ctx, m, vx, 1e-3, vp)
+        L.phip_vec_axpy(comm.ctx, m, vr, -1e-3, vw)
+        L.phip_vec_pointwise_mult_reduce(comm.ctx, m, vz, vd, vr, 0, C.byref(tk))
+
+    def aypx():
+        L.phip_vec_aypx(comm.ctx, m, vp, 0.5, vz)
+        L.phip_stream(comm.ctx)   # launches what is pending: one AYPX per launch, as inside the iteration
+
+    vec_ms = {}
+    for name, fn in (("cg_batch", cg_batch), ("aypx", aypx)):
+        for _ in range(10):
+            fn()
+        dsync()
+        vec_ms[name] = min(fmt_probe.time_region(fn, reps) for _ in range(3))
+    for v in vecs:
+        fmt_probe.free(v)
+
     tot_bytes = np.array([float(iter_bytes), float(dt), float(spmv_ms), float(spmv_bytes + spmv_add_bytes), float(b2b_ms)])
     if dist is not None:
         import torch
@@ -237,6 +263,13 @@ def main():
                          "note": "achieved = ALGORITHMIC CSR bytes (12 nz + 20 m + 4, SURVEY.md 8d) / launch time; the stencil layouts stream fewer bytes (layout_*: SELL-dict 9 B/nz; 1 B/nz when the matrix has <= 256 distinct (diagonal, value) pairs; 4 B/row when <= 32; all lossless, same bits; PHIP_VALUE_DICT=0 streams the values), and the 128^3 working set fits the 256 MiB Infinity Cache, so achieved can exceed the HBM peak",
                          "how": "%d launches back to back between two hipEvents on the library's compute stream, best of 3 (rocprofv3 average of the same kernel: profiles/)" % reps,
                          "avg_launch_us_inside_cg_event_pairs": round(spmv_ms * 1e3, 2), "achievable_peak_note": "6.29 TB/s measured float4 copy (MI355X_MICROARCH.md)"},
+            "vector_kernels": {
+                "bound": "hbm (here: Infinity Cache, the iteration's working set fits it)" if 8 * m * 7 + layout_bytes < (200 << 20) else "hbm",
+                "cg_batch": {"kernel": "cg_update_kernel", "what": "VecAXPY(X,a,P) + VecAXPY(R,-a,W) + VecPointwiseMult(Z,D,R) with 3 fused sums, one launch",
+                             "bytes_per_launch": 64 * m, "avg_launch_us": round(vec_ms["cg_batch"] * 1e3, 2),
+                             "GBps": round(64 * m / (vec_ms["cg_batch"] * 1e-3) / 1e9, 1), "frac": round(64 * m / (vec_ms["cg_batch"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                "aypx": {"kernel": "ew_kernel<AYPX>", "bytes_per_launch": 24 * m, "avg_launch_us": round(vec_ms["aypx"] * 1e3, 2),
+                         "GBps": round(24 * m / (vec_ms["aypx"] * 1e-3) / 1e9, 1), "frac": round(24 * m / (vec_ms["aypx"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}},
             "final_rnorm": res["rnorm"], "setup_s": round(setup_s, 2),
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -308,6 +308,81 @@ __global__ __launch_bounds__(PHIP_THREADS) void ew_batch_kernel(int32_t n, EwBat
   }
 }
 
+/* The batch KSPCG produces in every iteration (cg.c:222-229), written out: VecAXPY(X,a,P); VecAXPY(R,b,W); Z = D .* R with the three
+   sums.  The generic kernel above walks the operations one after the other, each waiting for its own loads; here the five operands are
+   requested together, the new R goes to the product through a register, and nothing is read twice.  Same expressions (ew_apply), same
+   entry order per thread, same grid: the bits of the generic kernel.  RFIRST: the product was called as Z = R .* D, else Z = D .* R. */
+template <bool RFIRST>
+__global__ __launch_bounds__(PHIP_THREADS) void cg_update_kernel(int32_t n, double *__restrict__ x, const double *__restrict__ p, double a, double *__restrict__ r,
+                                                                 const double *__restrict__ w, double b, double *__restrict__ z, const double *__restrict__ d,
+                                                                 RedCtl ctl)
+{
+  __shared__ double lds[12];
+  double            acc[3] = {0.0, 0.0, 0.0};
+  const int64_t     n2 = n >> 1;
+  const int64_t     stride = (int64_t)gridDim.x * PHIP_THREADS;
+  constexpr int     UN = 2;
+  for (int64_t i0 = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; i0 < n2; i0 += UN * stride) {
+    double2 xv[UN], pv[UN], rv[UN], wv[UN], dv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int64_t i = i0 + u * stride;
+      xv[u] = pv[u] = rv[u] = wv[u] = dv[u] = make_double2(0.0, 0.0);
+      if (i < n2) {
+        xv[u] = reinterpret_cast<const double2 *>(x)[i]; pv[u] = reinterpret_cast<const double2 *>(p)[i];
+        rv[u] = reinterpret_cast<const double2 *>(r)[i]; wv[u] = reinterpret_cast<const double2 *>(w)[i];
+        dv[u] = reinterpret_cast<const double2 *>(d)[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int64_t i = i0 + u * stride;
+      if (i < n2) {
+        double2 xn, rn, o;
+        xn.x = ew_apply<EW_AXPY>(a, 0, 0, pv[u].x, xv[u].x, 0.0); xn.y = ew_apply<EW_AXPY>(a, 0, 0, pv[u].y, xv[u].y, 0.0);
+        rn.x = ew_apply<EW_AXPY>(b, 0, 0, wv[u].x, rv[u].x, 0.0); rn.y = ew_apply<EW_AXPY>(b, 0, 0, wv[u].y, rv[u].y, 0.0);
+        const double2 f = RFIRST ? rn : dv[u], g = RFIRST ? dv[u] : rn; /* Z = f .* g */
+        o.x = ew_apply<EW_PMULT>(0, 0, 0, f.x, g.x, 0.0); o.y = ew_apply<EW_PMULT>(0, 0, 0, f.y, g.y, 0.0);
+        reinterpret_cast<double2 *>(x)[i] = xn;
+        reinterpret_cast<double2 *>(r)[i] = rn;
+        reinterpret_cast<double2 *>(z)[i] = o;
+        acc[0] += o.x * o.x + o.y * o.y;
+        acc[1] += o.x * f.x + o.y * f.y;
+        acc[2] += o.x * g.x + o.y * g.y;
+      }
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int32_t i = n - 1;
+    x[i] = ew_apply<EW_AXPY>(a, 0, 0, p[i], x[i], 0.0);
+    const double rn = ew_apply<EW_AXPY>(b, 0, 0, w[i], r[i], 0.0);
+    r[i] = rn;
+    const double f = RFIRST ? rn : d[i], g = RFIRST ? d[i] : rn;
+    const double o = ew_apply<EW_PMULT>(0, 0, 0, f, g, 0.0);
+    z[i] = o;
+    acc[0] += o * o; acc[1] += o * f; acc[2] += o * g;
+  }
+  block_sum<3>(acc, lds);
+  __syncthreads();
+  reduce_tail<3, 0>(acc, lds, ctl);
+}
+
+/* does the batch (two pending operations + the reducing product) have the shape cg_update_kernel is written for?  All seven arrays
+   distinct except that the second AXPY's result is one factor of the product. */
+static int cg_update_shape(const EwBatch &B)
+{
+  if (B.nops != 3) return 0;
+  const phip_ctx_s::phip_ew_op &o0 = B.op[0], &o1 = B.op[1], &o2 = B.op[2];
+  if (o0.op != EW_AXPY || o1.op != EW_AXPY || o2.op != EW_PMULT) return 0;
+  if (o0.y != o0.out || o1.y != o1.out) return 0;                       /* launch_ew<EW_AXPY>: x = the other vector, y = out */
+  const int rfirst = o2.x == o1.out ? 1 : (o2.y == o1.out ? 0 : -1);
+  if (rfirst < 0) return 0;
+  const double *dd = rfirst ? o2.y : o2.x;
+  const double *all[7] = {o0.out, o0.x, o1.out, o1.x, o2.out, dd, NULL};
+  for (int i = 0; i < 6; i++) for (int j = i + 1; j < 6; j++) if (all[i] == all[j]) return 0;
+  return rfirst ? 2 : 1;
+}
+
 /* ---- host launchers ---------------------------------------------------------------------------- */
 #define EW_GRID(n) phip_grid_for((n) / 2 + 1, 4, 2048)
 #define CHECK_CTX_Q(c, name) do { PHIP_REQUIRE((c), PHIP_ERR_ARG_NULL, name ": null context"); PHIP_NEED_DEVICE((c), name); } while (0)
@@ -474,7 +549,15 @@ extern "C" int phip_vec_pointwise_mult_reduce(phip_ctx c, int32_t n, double *d_w
     c->ew_n = 0;
     static const int red_grid_env = getenv("PHIP_EW_RED_GRID") ? atoi(getenv("PHIP_EW_RED_GRID")) : 0;
     const int        red_grid = (red_grid_env > 0 && red_grid_env <= PHIP_RED_BLOCKS) ? red_grid_env : PHIP_RED_GRID;
-    hipLaunchKernelGGL((ew_batch_kernel<true>), dim3(phip_grid_for((int64_t)n / 2 + 1, 4, red_grid)), dim3(PHIP_THREADS), 0, c->stream, n, B, ctl);
+    const dim3       grid(phip_grid_for((int64_t)n / 2 + 1, 4, red_grid));
+    static const int cgk_env = getenv("PHIP_CG_UPDATE_KERNEL") ? atoi(getenv("PHIP_CG_UPDATE_KERNEL")) : 1;
+    const int        shape = cgk_env ? cg_update_shape(B) : 0;
+    if (shape == 2)
+      hipLaunchKernelGGL((cg_update_kernel<true>), grid, dim3(PHIP_THREADS), 0, c->stream, n, B.op[0].out, B.op[0].x, B.op[0].a, B.op[1].out, B.op[1].x, B.op[1].a, d_w, d_y, ctl);
+    else if (shape == 1)
+      hipLaunchKernelGGL((cg_update_kernel<false>), grid, dim3(PHIP_THREADS), 0, c->stream, n, B.op[0].out, B.op[0].x, B.op[0].a, B.op[1].out, B.op[1].x, B.op[1].a, d_w, d_x, ctl);
+    else
+      hipLaunchKernelGGL((ew_batch_kernel<true>), grid, dim3(PHIP_THREADS), 0, c->stream, n, B, ctl);
     PHIP_CHECK_HIP(hipGetLastError());
     return 0;
   }

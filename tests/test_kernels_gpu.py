@@ -726,6 +726,61 @@ def test_byproduct_tickets(ctx, orc):
         ctx.free(p)
 
 
+@pytest.mark.parametrize("n", [1, 2, 1001, 300000, 2097153])
+def test_cg_update_batch(orc, n):
+    """VecAXPY(X,a,P); VecAXPY(R,b,W); Z = D.*R (or R.*D) with the three sums -- the batch of a KSPCG iteration -- runs in a kernel of its
+    own (operands requested together, the new R handed over in a register): same bits as one launch per operation, sums within round-off;
+    a batch that only looks similar (an operand shared between the operations) takes the generic kernel and gives the same."""
+    import ctypes as C
+    from petsc_amd import capi
+    from petsc_amd.capi import Ticket
+    rng = np.random.default_rng(9)
+    x0, p0, r0, w0, d0 = (rng.standard_normal(n) for _ in range(5))
+
+    def run(c):
+        L = c.lib
+        out = []
+        for variant in range(3):
+            dx, dp, dr, dw, dd = (c.to_device(v) for v in (x0, p0, r0, w0, d0))
+            dz = c.to_device(np.zeros(n))
+            c.check(L.phip_vec_axpy(c.h, n, dx, 0.375, dp))
+            c.check(L.phip_vec_axpy(c.h, n, dr, -0.375, dp if variant == 2 else dw))      # variant 2: P appears twice -> generic kernel
+            t = Ticket()
+            if variant == 1:
+                c.check(L.phip_vec_pointwise_mult_reduce(c.h, n, dz, dr, dd, 1, C.byref(t)))   # Z = R .* D
+            else:
+                c.check(L.phip_vec_pointwise_mult_reduce(c.h, n, dz, dd, dr, 1, C.byref(t)))   # Z = D .* R
+            red = np.zeros(3)
+            c.check(L.phip_ticket_wait(c.h, C.byref(t), red.ctypes.data_as(C.POINTER(C.c_double))))
+            out.append([c.to_host(v, n) for v in (dx, dr, dz)] + [red])
+            for v in (dx, dp, dr, dw, dd, dz):
+                c.free(v)
+        return out
+
+    c1 = capi.Context(0)
+    got = run(c1)
+    c1.close()
+    os.environ["PHIP_EW_BATCH"] = "0"
+    try:
+        c0 = capi.Context(0)
+    finally:
+        del os.environ["PHIP_EW_BATCH"]
+    ref = run(c0)
+    c0.close()
+    for variant, (g, r) in enumerate(zip(got, ref)):
+        for a, b in zip(g[:3], r[:3]):
+            np.testing.assert_array_equal(a, b)
+        x = x0 + 0.375 * p0
+        rr = r0 - 0.375 * (p0 if variant == 2 else w0)
+        z = d0 * rr
+        f, gg = (rr, d0) if variant == 1 else (d0, rr)
+        assert np.abs(g[0] - x).max() <= 1e-15 * max(1.0, np.abs(x).max()) * 4
+        assert np.abs(g[2] - z).max() <= 1e-14 * max(1.0, np.abs(z).max())
+        exact = np.array([z @ z, z @ f, z @ gg])
+        scale = max(1.0, (z * z).sum(), np.abs(z * f).sum(), np.abs(z * gg).sum())
+        assert np.abs(g[3] - exact).max() <= 1e-12 * scale and np.abs(g[3] - r[3]).max() <= 1e-12 * scale
+
+
 @pytest.mark.parametrize("n", [1, 2, 7, 1000, 300001])
 def test_batched_elementwise_ops(orc, n):
     """Elementwise operations wait in the context and leave in one launch (up to 4, call order kept per entry).  Chains in which each
