@@ -196,7 +196,8 @@ def main():
     # VecAYPX(P,b,Z) (cg.c:252: 2 read, 1 written)
     from petsc_amd.capi import Ticket
     vecs = [fmt_probe.to_device(np.linspace(0.1, 1.0, m) * (k + 1)) for k in range(7)]
-    vx, vp, vr, vw, vd, vz, _ = vecs
+    vx, vp, vr, vw, vd, _, _ = vecs
+    vz = vw   # KSPCG keeps W and Z in one work vector (cg.c:106)
     tk = Ticket()
 
     def cg_batch():

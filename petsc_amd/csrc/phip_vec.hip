@@ -311,11 +311,11 @@ __global__ __launch_bounds__(PHIP_THREADS) void ew_batch_kernel(int32_t n, EwBat
 /* The batch KSPCG produces in every iteration (cg.c:222-229), written out: VecAXPY(X,a,P); VecAXPY(R,b,W); Z = D .* R with the three
    sums.  The generic kernel above walks the operations one after the other, each waiting for its own loads; here the five operands are
    requested together, the new R goes to the product through a register, and nothing is read twice.  Same expressions (ew_apply), same
-   entry order per thread, same grid: the bits of the generic kernel.  RFIRST: the product was called as Z = R .* D, else Z = D .* R. */
+   entry order per thread, same grid: the bits of the generic kernel.  RFIRST: the product was called as Z = R .* D, else Z = D .* R.
+   Z may be W (KSPCG keeps both in one work vector, cg.c:106: W = Z): a thread has read its entries of W before it stores them as Z. */
 template <bool RFIRST>
 __global__ __launch_bounds__(PHIP_THREADS) void cg_update_kernel(int32_t n, double *__restrict__ x, const double *__restrict__ p, double a, double *__restrict__ r,
-                                                                 const double *__restrict__ w, double b, double *__restrict__ z, const double *__restrict__ d,
-                                                                 RedCtl ctl)
+                                                                 const double *w, double b, double *z, const double *__restrict__ d, RedCtl ctl)
 {
   __shared__ double lds[12];
   double            acc[3] = {0.0, 0.0, 0.0};
@@ -367,8 +367,8 @@ __global__ __launch_bounds__(PHIP_THREADS) void cg_update_kernel(int32_t n, doub
   reduce_tail<3, 0>(acc, lds, ctl);
 }
 
-/* does the batch (two pending operations + the reducing product) have the shape cg_update_kernel is written for?  All seven arrays
-   distinct except that the second AXPY's result is one factor of the product. */
+/* does the batch (two pending operations + the reducing product) have the shape cg_update_kernel is written for?  The second AXPY's
+   result is one factor of the product; otherwise the arrays are distinct, except that the product may overwrite W. */
 static int cg_update_shape(const EwBatch &B)
 {
   if (B.nops != 3) return 0;
@@ -378,8 +378,8 @@ static int cg_update_shape(const EwBatch &B)
   const int rfirst = o2.x == o1.out ? 1 : (o2.y == o1.out ? 0 : -1);
   if (rfirst < 0) return 0;
   const double *dd = rfirst ? o2.y : o2.x;
-  const double *all[7] = {o0.out, o0.x, o1.out, o1.x, o2.out, dd, NULL};
-  for (int i = 0; i < 6; i++) for (int j = i + 1; j < 6; j++) if (all[i] == all[j]) return 0;
+  const double *all[6] = {o0.out, o0.x, o1.out, dd, o1.x, o2.out}; /* X P R D W Z: all distinct, except that Z may be W */
+  for (int i = 0; i < 6; i++) for (int j = i + 1; j < 6; j++) if (all[i] == all[j] && !(i == 4 && j == 5)) return 0;
   return rfirst ? 2 : 1;
 }
 

@@ -740,9 +740,9 @@ def test_cg_update_batch(orc, n):
     def run(c):
         L = c.lib
         out = []
-        for variant in range(3):
+        for variant in range(4):
             dx, dp, dr, dw, dd = (c.to_device(v) for v in (x0, p0, r0, w0, d0))
-            dz = c.to_device(np.zeros(n))
+            dz = dw if variant == 3 else c.to_device(np.zeros(n))                        # variant 3: Z is W, as in KSPCG (cg.c:106)
             c.check(L.phip_vec_axpy(c.h, n, dx, 0.375, dp))
             c.check(L.phip_vec_axpy(c.h, n, dr, -0.375, dp if variant == 2 else dw))      # variant 2: P appears twice -> generic kernel
             t = Ticket()
@@ -753,7 +753,7 @@ def test_cg_update_batch(orc, n):
             red = np.zeros(3)
             c.check(L.phip_ticket_wait(c.h, C.byref(t), red.ctypes.data_as(C.POINTER(C.c_double))))
             out.append([c.to_host(v, n) for v in (dx, dr, dz)] + [red])
-            for v in (dx, dp, dr, dw, dd, dz):
+            for v in (dx, dp, dr, dw, dd) + (() if variant == 3 else (dz,)):
                 c.free(v)
         return out
 
