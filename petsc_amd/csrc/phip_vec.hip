@@ -150,17 +150,24 @@ __device__ __forceinline__ double ew_apply(double a, double b, double g, double 
   return 0.0;
 }
 
+__device__ __forceinline__ double2 ld2(const double *p, int64_t i, bool nt)
+{
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  if (nt) { const v2d q = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p) + i); return make_double2(q.x, q.y); }
+  return reinterpret_cast<const double2 *>(p)[i];
+}
+
 /* out = f(x, y, z); any of x,y,z may alias out (pure elementwise) */
 template <int OP, bool HX, bool HY, bool HZ>
-__global__ __launch_bounds__(PHIP_THREADS) void ew_kernel(int32_t n, double *out, const double *x, const double *y, const double *z, double a, double b, double g)
+__global__ __launch_bounds__(PHIP_THREADS) void ew_kernel(int32_t n, double *out, const double *x, const double *y, const double *z, double a, double b, double g, int nt)
 {
   const int64_t n2 = n >> 1;
   const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
   for (int64_t i = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; i < n2; i += stride) {
     double2 xv = {0, 0}, yv = {0, 0}, zv = {0, 0}, o;
-    if (HX) xv = reinterpret_cast<const double2 *>(x)[i];
-    if (HY) yv = reinterpret_cast<const double2 *>(y)[i];
-    if (HZ) zv = reinterpret_cast<const double2 *>(z)[i];
+    if (HX) xv = ld2(x, i, nt);
+    if (HY) yv = ld2(y, i, nt);
+    if (HZ) zv = ld2(z, i, nt);
     o.x = ew_apply<OP>(a, b, g, xv.x, yv.x, zv.x);
     o.y = ew_apply<OP>(a, b, g, xv.y, yv.y, zv.y);
     reinterpret_cast<double2 *>(out)[i] = o;
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void ew_batch_kernel(int32_t n, EwBat
    Z may be W (KSPCG keeps both in one work vector, cg.c:106: W = Z): a thread has read its entries of W before it stores them as Z. */
 template <bool RFIRST>
 __global__ __launch_bounds__(PHIP_THREADS) void cg_update_kernel(int32_t n, double *__restrict__ x, const double *__restrict__ p, double a, double *__restrict__ r,
-                                                                 const double *w, double b, double *z, const double *__restrict__ d, RedCtl ctl)
+                                                                 const double *w, double b, double *z, const double *__restrict__ d, RedCtl ctl, int nt)
 {
   __shared__ double lds[12];
   double            acc[3] = {0.0, 0.0, 0.0};
@@ -340,9 +347,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void cg_update_kernel(int32_t n, doub
       const int64_t i = i0 + u * stride;
       xv[u] = pv[u] = rv[u] = wv[u] = dv[u] = make_double2(0.0, 0.0);
       if (i < n2) {
-        xv[u] = reinterpret_cast<const double2 *>(x)[i]; pv[u] = reinterpret_cast<const double2 *>(p)[i];
-        rv[u] = reinterpret_cast<const double2 *>(r)[i]; wv[u] = reinterpret_cast<const double2 *>(w)[i];
-        dv[u] = reinterpret_cast<const double2 *>(d)[i];
+        xv[u] = ld2(x, i, nt); pv[u] = ld2(p, i, nt); rv[u] = ld2(r, i, nt); wv[u] = ld2(w, i, nt); dv[u] = ld2(d, i, nt);
       }
     }
 #pragma unroll
@@ -401,10 +406,21 @@ static int cg_update_shape(const EwBatch &B)
 #define CHECK_CTX(c, name) do { CHECK_CTX_Q(c, name); PHIP_FLUSH(c); } while (0)
 #define CHECK_N(n, name) PHIP_REQUIRE((n) >= 0, PHIP_ERR_ARG_OUTOFRANGE, name ": negative length %d", (n))
 
+/* Vectors of 64 MiB and more are streamed with non-temporal loads: a Krylov iteration over them has a working set of several times the
+   256 MiB Infinity Cache, nothing an elementwise kernel reads is found there again, and what it would displace (the SpMV's x, the
+   matrix's masks) is.  The kernels themselves take the same time; the iteration gains: KSPCG 7-point 256^3 2335 -> 2543 it/s, 27-point
+   256^3 1755 -> 1845; 7-point 192^3 (57 MB vectors) 5946 -> 6010, 128^3 (cache-resident) 16.2 k -> 15.3 k, hence the limit.
+   PHIP_EW_NT=0|1 overrides. */
+static inline int ew_nt(int32_t n)
+{
+  static const int env = getenv("PHIP_EW_NT") ? atoi(getenv("PHIP_EW_NT")) : -1;
+  return env >= 0 ? env : (n >= (8 << 20));
+}
+
 template <int OP, bool HX, bool HY, bool HZ>
 static int launch_ew_now(phip_ctx c, int32_t n, double *out, const double *x, const double *y, const double *z, double a, double b, double g)
 {
-  hipLaunchKernelGGL((ew_kernel<OP, HX, HY, HZ>), dim3(EW_GRID(n)), dim3(PHIP_THREADS), 0, c->stream, n, out, x, y, z, a, b, g);
+  hipLaunchKernelGGL((ew_kernel<OP, HX, HY, HZ>), dim3(EW_GRID(n)), dim3(PHIP_THREADS), 0, c->stream, n, out, x, y, z, a, b, g, ew_nt(n));
   PHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -564,9 +580,9 @@ extern "C" int phip_vec_pointwise_mult_reduce(phip_ctx c, int32_t n, double *d_w
     static const int cgk_env = getenv("PHIP_CG_UPDATE_KERNEL") ? atoi(getenv("PHIP_CG_UPDATE_KERNEL")) : 1;
     const int        shape = cgk_env ? cg_update_shape(B) : 0;
     if (shape == 2)
-      hipLaunchKernelGGL((cg_update_kernel<true>), grid, dim3(PHIP_THREADS), 0, c->stream, n, B.op[0].out, B.op[0].x, B.op[0].a, B.op[1].out, B.op[1].x, B.op[1].a, d_w, d_y, ctl);
+      hipLaunchKernelGGL((cg_update_kernel<true>), grid, dim3(PHIP_THREADS), 0, c->stream, n, B.op[0].out, B.op[0].x, B.op[0].a, B.op[1].out, B.op[1].x, B.op[1].a, d_w, d_y, ctl, ew_nt(n));
     else if (shape == 1)
-      hipLaunchKernelGGL((cg_update_kernel<false>), grid, dim3(PHIP_THREADS), 0, c->stream, n, B.op[0].out, B.op[0].x, B.op[0].a, B.op[1].out, B.op[1].x, B.op[1].a, d_w, d_x, ctl);
+      hipLaunchKernelGGL((cg_update_kernel<false>), grid, dim3(PHIP_THREADS), 0, c->stream, n, B.op[0].out, B.op[0].x, B.op[0].a, B.op[1].out, B.op[1].x, B.op[1].a, d_w, d_x, ctl, ew_nt(n));
     else
       hipLaunchKernelGGL((ew_batch_kernel<true>), grid, dim3(PHIP_THREADS), 0, c->stream, n, B, ctl);
     PHIP_CHECK_HIP(hipGetLastError());
