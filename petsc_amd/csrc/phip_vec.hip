@@ -157,6 +157,13 @@ __device__ __forceinline__ double2 ld2(const double *p, int64_t i, bool nt)
   return reinterpret_cast<const double2 *>(p)[i];
 }
 
+__device__ __forceinline__ void st2(double *p, int64_t i, const double2 v, bool nt)
+{
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  if (nt) { v2d q; q.x = v.x; q.y = v.y; __builtin_nontemporal_store(q, reinterpret_cast<v2d *>(p) + i); }
+  else reinterpret_cast<double2 *>(p)[i] = v;
+}
+
 /* out = f(x, y, z); any of x,y,z may alias out (pure elementwise) */
 template <int OP, bool HX, bool HY, bool HZ>
 __global__ __launch_bounds__(PHIP_THREADS) void ew_kernel(int32_t n, double *out, const double *x, const double *y, const double *z, double a, double b, double g, int nt)
@@ -165,9 +172,9 @@ __global__ __launch_bounds__(PHIP_THREADS) void ew_kernel(int32_t n, double *out
   const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
   for (int64_t i = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; i < n2; i += stride) {
     double2 xv = {0, 0}, yv = {0, 0}, zv = {0, 0}, o;
-    if (HX) xv = ld2(x, i, nt);
-    if (HY) yv = ld2(y, i, nt);
-    if (HZ) zv = ld2(z, i, nt);
+    if (HX) xv = ld2(x, i, nt & 1);
+    if (HY) yv = ld2(y, i, nt & 1);
+    if (HZ) zv = ld2(z, i, nt & 1);
     o.x = ew_apply<OP>(a, b, g, xv.x, yv.x, zv.x);
     o.y = ew_apply<OP>(a, b, g, xv.y, yv.y, zv.y);
     reinterpret_cast<double2 *>(out)[i] = o;
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void cg_update_kernel(int32_t n, doub
       const int64_t i = i0 + u * stride;
       xv[u] = pv[u] = rv[u] = wv[u] = dv[u] = make_double2(0.0, 0.0);
       if (i < n2) {
-        xv[u] = ld2(x, i, nt); pv[u] = ld2(p, i, nt); rv[u] = ld2(r, i, nt); wv[u] = ld2(w, i, nt); dv[u] = ld2(d, i, nt);
+        xv[u] = ld2(x, i, nt & 1); pv[u] = ld2(p, i, nt & 1); rv[u] = ld2(r, i, nt & 1); wv[u] = ld2(w, i, nt & 1); dv[u] = ld2(d, i, nt & 1);
       }
     }
 #pragma unroll
@@ -359,9 +366,9 @@ __global__ __launch_bounds__(PHIP_THREADS) void cg_update_kernel(int32_t n, doub
         rn.x = ew_apply<EW_AXPY>(b, 0, 0, wv[u].x, rv[u].x, 0.0); rn.y = ew_apply<EW_AXPY>(b, 0, 0, wv[u].y, rv[u].y, 0.0);
         const double2 f = RFIRST ? rn : dv[u], g = RFIRST ? dv[u] : rn; /* Z = f .* g */
         o.x = ew_apply<EW_PMULT>(0, 0, 0, f.x, g.x, 0.0); o.y = ew_apply<EW_PMULT>(0, 0, 0, f.y, g.y, 0.0);
-        reinterpret_cast<double2 *>(x)[i] = xn;
-        reinterpret_cast<double2 *>(r)[i] = rn;
-        reinterpret_cast<double2 *>(z)[i] = o;
+        st2(x, i, xn, nt & 2);
+        st2(r, i, rn, nt & 4);
+        st2(z, i, o, nt & 8);
         acc[0] += o.x * o.x + o.y * o.y;
         acc[1] += o.x * f.x + o.y * f.y;
         acc[2] += o.x * g.x + o.y * g.y;
@@ -414,7 +421,12 @@ static int cg_update_shape(const EwBatch &B)
 static inline int ew_nt(int32_t n)
 {
   static const int env = getenv("PHIP_EW_NT") ? atoi(getenv("PHIP_EW_NT")) : -1;
-  return env >= 0 ? env : (n >= (8 << 20));
+  /* cg_update_kernel also STORES X and R past the caches (bits 1 and 2 of PHIP_EW_NT_ST; nobody reads them before the next iteration,
+     several cache sizes later), but not Z, which VecAYPX reads next: KSPCG it/s with stores of none / X / X,R / X,R,Z non-temporal:
+     7-point 256^3 2542 / 2654 / 2759 / 2655; 27-point 256^3 1851 / 1916 / 1973 / 1924 */
+  static const int st = getenv("PHIP_EW_NT_ST") ? atoi(getenv("PHIP_EW_NT_ST")) : 3;
+  const int on = env >= 0 ? env : (n >= (8 << 20));
+  return on ? (1 | (st << 1)) : 0;
 }
 
 template <int OP, bool HX, bool HY, bool HZ>
