@@ -726,7 +726,7 @@ def test_byproduct_tickets(ctx, orc):
         ctx.free(p)
 
 
-@pytest.mark.parametrize("n", [1, 2, 1001, 300000, 2097153])
+@pytest.mark.parametrize("n", [1, 2, 1001, 300000, 2097153, 8388609])   # the last: 64 MiB vectors, the non-temporal loads and stores
 def test_cg_update_batch(orc, n):
     """VecAXPY(X,a,P); VecAXPY(R,b,W); Z = D.*R (or R.*D) with the three sums -- the batch of a KSPCG iteration -- runs in a kernel of its
     own (operands requested together, the new R handed over in a register): same bits as one launch per operation, sums within round-off;
