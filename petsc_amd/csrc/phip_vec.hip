@@ -413,7 +413,7 @@ static int cg_update_shape(const EwBatch &B)
 #define CHECK_CTX(c, name) do { CHECK_CTX_Q(c, name); PHIP_FLUSH(c); } while (0)
 #define CHECK_N(n, name) PHIP_REQUIRE((n) >= 0, PHIP_ERR_ARG_OUTOFRANGE, name ": negative length %d", (n))
 
-/* Vectors of 64 MiB and more are streamed with non-temporal loads: a Krylov iteration over them has a working set of several times the
+/* Vectors of 48 MiB and more are streamed with non-temporal loads: a Krylov iteration over them has a working set of several times the
    256 MiB Infinity Cache, nothing an elementwise kernel reads is found there again, and what it would displace (the SpMV's x, the
    matrix's masks) is.  The kernels themselves take the same time; the iteration gains: KSPCG 7-point 256^3 2335 -> 2543 it/s, 27-point
    256^3 1755 -> 1845; 7-point 192^3 (57 MB vectors) 5946 -> 6010, 128^3 (cache-resident) 16.2 k -> 15.3 k, hence the limit.
@@ -425,7 +425,7 @@ static inline int ew_nt(int32_t n)
      several cache sizes later), but not Z, which VecAYPX reads next: KSPCG it/s with stores of none / X / X,R / X,R,Z non-temporal:
      7-point 256^3 2542 / 2654 / 2759 / 2655; 27-point 256^3 1851 / 1916 / 1973 / 1924 */
   static const int st = getenv("PHIP_EW_NT_ST") ? atoi(getenv("PHIP_EW_NT_ST")) : 3;
-  const int on = env >= 0 ? env : (n >= (8 << 20));
+  const int on = env >= 0 ? env : (n >= (6 << 20)); /* 48 MiB: 7-point 192^3 (57 MB) 5933 -> 6041 it/s, 160^3 (33 MB) 10.1 k -> 9.5 k */
   return on ? (1 | (st << 1)) : 0;
 }
 
