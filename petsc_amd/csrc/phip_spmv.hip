@@ -450,7 +450,7 @@ template <bool DOT, int U>
 __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmask_kernel(int32_t m, int32_t n, int32_t nslices, const uint32_t *__restrict__ rmask,
                                                                   const int32_t *__restrict__ poffs, const double *__restrict__ pvals,
                                                                   const double *__restrict__ x, const double *__restrict__ yin, double *__restrict__ yout,
-                                                                  int add, const double *__restrict__ dotv, double *__restrict__ wgpart, RedCtl ctl)
+                                                                  int add, const double *__restrict__ dotv, double *__restrict__ wgpart, RedCtl ctl, int nty)
 {
 #pragma clang fp contract(off)
   __shared__ double lds[4];
@@ -503,7 +503,10 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmask_kernel(int32_t m, int
         }
       }
     }
-    if (actB) *reinterpret_cast<double2 *>(yout + r0) = make_double2(sA, sB);
+    if (actB) {
+      if (nty) { typedef double v2d __attribute__((ext_vector_type(2))); v2d q; q.x = sA; q.y = sB; __builtin_nontemporal_store(q, reinterpret_cast<v2d *>(yout + r0)); }
+      else *reinterpret_cast<double2 *>(yout + r0) = make_double2(sA, sB);
+    }
     else if (actA) yout[r0] = sA;
     if (DOT) {
       if (actA) dacc += dvA * (sA - yA);
@@ -1140,13 +1143,18 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     static const int dm_dot_env = getenv("PHIP_DMASK_DOT") ? atoi(getenv("PHIP_DMASK_DOT")) : -1;
     if (vd && A->dm_built && A->dm_on && (!DOT || g_dm_mode == 2 || (dm_dot_env >= 0 ? dm_dot_env != 0 : A->nnz >= 40000000))) {
       const unsigned dgrid = (unsigned)A->sell_nslices;
+      /* results of 64 MiB and more leave with non-temporal stores: they do not push x out of the caches while the product still
+         gathers from it (7-point 256^3: 97.9 -> 80.2 us, KSPCG 2759 -> 2805 it/s; 27-point 256^3: 227 -> 205 us; 192^3, 57 MB: no
+         change).  PHIP_SPMV_NT_Y=0|1 overrides. */
+      static const int nty_env = getenv("PHIP_SPMV_NT_Y") ? atoi(getenv("PHIP_SPMV_NT_Y")) : -1;
+      const int        nty = nty_env >= 0 ? nty_env : (A->m >= (8 << 20));
       double        *part = DOT ? A->d_dotpart : NULL;
       if (dm_u_env == 8)
         hipLaunchKernelGGL((spmv_dmask_kernel<DOT, 8>), dim3(dgrid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_rmask, A->d_dmoffs, A->d_dmvals, d_x,
-                           d_yin, d_yout, add, d_v, part, ctl);
+                           d_yin, d_yout, add, d_v, part, ctl, nty);
       else
         hipLaunchKernelGGL((spmv_dmask_kernel<DOT, 4>), dim3(dgrid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_rmask, A->d_dmoffs, A->d_dmvals, d_x,
-                           d_yin, d_yout, add, d_v, part, ctl);
+                           d_yin, d_yout, add, d_v, part, ctl, nty);
       if (DOT) hipLaunchKernelGGL(dot_partials_kernel, dim3(1), dim3(PHIP_THREADS), 0, st, A->d_dotpart, A->sell_nslices, ctl);
     }
     else if (vd) {

@@ -407,6 +407,38 @@ def test_value_pair_dictionary(ctx, orc):
     ctx.check(L.phip_mat_destroy(A))
 
 
+def test_spmv_large_result_nontemporal(ctx, orc):
+    """A product with more than 8 M rows stores its result with non-temporal stores (diagonal-mask kernel): same bits as the oracle,
+    for the plain product, MultAdd and the product with the fused dot (which at this size also goes through the masks)."""
+    import ctypes as C
+    from petsc_amd import generators as G
+    from petsc_amd.capi import Ticket
+    L = ctx.lib
+    ai, aj, aa = G.laplace2d_5pt(2900, 2900)
+    m = len(ai) - 1
+    assert m >= (8 << 20) and len(aj) >= 40000000
+    x, y0 = G.random_vector(m), G.random_vector(m, 3)
+    A = ctx.mat_create(m, m, ai, aj, aa)
+    db, du, dn = C.c_int(), C.c_int(), C.c_int32()
+    ctx.check(L.phip_mat_diag_mask_info(A, C.byref(db), C.byref(du), C.byref(dn)))
+    assert (db.value, du.value) == (1, 1)
+    dx, dy, dy0 = ctx.to_device(x), ctx.to_device(np.zeros(m)), ctx.to_device(y0)
+    ctx.check(L.phip_mat_mult(A, dx, dy))
+    yo = orc.matmult(ai, aj, aa, x)
+    np.testing.assert_array_equal(ctx.to_host(dy, m), yo)
+    ctx.check(L.phip_mat_multadd(A, dx, dy0, dy))
+    np.testing.assert_array_equal(ctx.to_host(dy, m), orc.matmultadd(ai, aj, aa, x, y0))
+    t = Ticket()
+    val = np.zeros(1)
+    ctx.check(L.phip_mat_mult_dot(A, dx, dy, dx, 1, C.byref(t)))
+    ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t), val.ctypes.data_as(C.POINTER(C.c_double))))
+    np.testing.assert_array_equal(ctx.to_host(dy, m), yo)
+    assert abs(val[0] - x @ yo) <= 1e-12 * np.abs(x * yo).sum()
+    for p in (dx, dy, dy0):
+        ctx.free(p)
+    ctx.check(L.phip_mat_destroy(A))
+
+
 def test_hot_column_order(ctx, orc):
     """The hot-column order (columns numbered by descending use, x copied into that order by every product) leaves every product and
     every summation order as it was: bit-identical results for mult, multadd, the fused dot, the transpose and the compressed-row
