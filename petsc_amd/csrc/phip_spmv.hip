@@ -140,6 +140,13 @@ __device__ __forceinline__ uchar2 ld_stream(const uchar2 *p)
   return *p;
 }
 
+/* two adjacent results; nt: past the caches (results of PHIP_NT_RESULT_ROWS rows and more, see launch_spmv_t) */
+__device__ __forceinline__ void st_result2(double *p, double a, double b, bool nt)
+{
+  if (nt) { typedef double v2d __attribute__((ext_vector_type(2))); v2d q; q.x = a; q.y = b; __builtin_nontemporal_store(q, reinterpret_cast<v2d *>(p)); }
+  else *reinterpret_cast<double2 *>(p) = make_double2(a, b);
+}
+
 template <int TPR, bool DOT>
 __device__ __forceinline__ void spmv_reduce_rows(const double *prod, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx,
                                                  const double *__restrict__ yin, double *__restrict__ yout, int r0, int r1, int abase,
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
                                                                  const double *__restrict__ sval, const uint8_t *__restrict__ scode,
                                                                  const int32_t *__restrict__ soffs, int noffs, const int32_t *__restrict__ scl, int ncl,
                                                                  const double *__restrict__ x, const double *__restrict__ yin, double *__restrict__ yout, int add,
-                                                                 const double *__restrict__ dotv, RedCtl ctl)
+                                                                 const double *__restrict__ dotv, RedCtl ctl, int nty)
 {
 #pragma clang fp contract(off) /* multiply and add round separately, as the reference's compiled loop does (no FMA) */
   extern __shared__ __attribute__((aligned(16))) double xs[]; /* STAGE: the x segments */
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
         if (s + u < l1) s1 = s1 + v[u].y * xb[u];
       }
     }
-    if (has1) *reinterpret_cast<double2 *>(yout + r0) = make_double2(s0, s1);
+    if (has1) st_result2(yout + r0, s0, s1, nty);
     else if (act) yout[r0] = s0;
     if (DOT && act) {
       dacc += dv0 * (s0 - y0);
@@ -368,7 +375,7 @@ template <bool NT, bool DOT, int G>
 __global__ __launch_bounds__(PHIP_THREADS) void spmv_pair_kernel(int32_t m, int32_t nslices, const int64_t *__restrict__ pptr, const uint8_t *__restrict__ slen,
                                                                  const uint32_t *__restrict__ pgrp, const int32_t *__restrict__ poffs, const double *__restrict__ pvals,
                                                                  int npairs, const double *__restrict__ x, const double *__restrict__ yin, double *__restrict__ yout,
-                                                                 int add, const double *__restrict__ dotv, RedCtl ctl)
+                                                                 int add, const double *__restrict__ dotv, RedCtl ctl, int nty)
 {
 #pragma clang fp contract(off)
   __shared__ int4   tab[SELL_MAX_OFFS]; /* x: diagonal, z/w: the value's low and high words */
@@ -419,8 +426,8 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_pair_kernel(int32_t m, int3
         if (4 * g + j < lB) sB = sB + vb[j] * xb[j];
       }
     }
-    if (actA) yout[rA] = sA;
-    if (actB) yout[rB] = sB;
+    if (nty) { if (actA) __builtin_nontemporal_store(sA, yout + rA); if (actB) __builtin_nontemporal_store(sB, yout + rB); }
+    else { if (actA) yout[rA] = sA; if (actB) yout[rB] = sB; }
     if (DOT) {
       if (actA) dacc += dvA * (sA - yA);
       if (actB) dacc += dvB * (sB - yB);
@@ -504,8 +511,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmask_kernel(int32_t m, int
       }
     }
     if (actB) {
-      if (nty) { typedef double v2d __attribute__((ext_vector_type(2))); v2d q; q.x = sA; q.y = sB; __builtin_nontemporal_store(q, reinterpret_cast<v2d *>(yout + r0)); }
-      else *reinterpret_cast<double2 *>(yout + r0) = make_double2(sA, sB);
+      st_result2(yout + r0, sA, sB, nty);
     }
     else if (actA) yout[r0] = sA;
     if (DOT) {
@@ -1109,6 +1115,11 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     const int      dot_cap = (dot_grid_env > 0 && dot_grid_env <= PHIP_RED_BLOCKS) ? dot_grid_env : 1024;
     const unsigned grid = DOT ? (unsigned)(A->sell_nslices < dot_cap ? A->sell_nslices : dot_cap) : (unsigned)A->sell_nslices;
     const bool     nt = 9 * A->sell_padded > PHIP_NT_MATRIX_BYTES;
+    /* results of 64 MiB and more leave with non-temporal stores: they do not push x out of the caches while the product still
+       gathers from it (diagonal masks, 7-point 256^3: 97.9 -> 80.2 us, KSPCG 2759 -> 2805 it/s; 27-point 256^3: 227 -> 205 us;
+       192^3, 57 MB: no change).  PHIP_SPMV_NT_Y=0|1 overrides. */
+    static const int nty_env = getenv("PHIP_SPMV_NT_Y") ? atoi(getenv("PHIP_SPMV_NT_Y")) : -1;
+    const int        nty = nty_env >= 0 ? nty_env : (A->m >= (8 << 20));
     /* LDS staging of x is correct but measured SLOWER than gathering through L1/L2 (7-point 128^3: 26.9 -> 31.8 us; 27-point 160^3:
        206 -> 220 us; with values from the pair dictionary instead of the stream, 27-point 256^3: 327 -> 539 us): the gathers are not
        what bounds this kernel.  Off unless PHIP_SELL_STAGE=1. */
@@ -1118,7 +1129,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
 #define SELL_LAUNCH2(NTv, STv, Uv)                                                                                                                        \
   hipLaunchKernelGGL((spmv_sell_kernel<NTv, DOT, STv, Uv>), dim3(grid), dim3(PHIP_THREADS), (STv) ? sizeof(double) * (size_t)A->stage_lds_doubles : 0, st, A->m, \
                      A->n, A->sell_nslices, A->d_sptr, A->d_slen, A->d_sval, A->d_scode, (STv) ? A->d_sldsoff : A->d_soffs, A->sell_noffs, A->d_scl,      \
-                     A->stage_ncl, d_x, d_yin, d_yout, add, d_v, ctl)
+                     A->stage_ncl, d_x, d_yin, d_yout, add, d_v, ctl, nty)
     /* slots requested per lane before the gathers start: 8 for long rows (27-point 192^3: 361.9 -> 349.7 us), 4 otherwise (rows of 7
        never fill a batch of 8: 27.1 -> 36.1 us); PHIP_SELL_UNROLL=4|8 overrides */
     static const int unroll_env = getenv("PHIP_SELL_UNROLL") ? atoi(getenv("PHIP_SELL_UNROLL")) : 0;
@@ -1143,11 +1154,6 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     static const int dm_dot_env = getenv("PHIP_DMASK_DOT") ? atoi(getenv("PHIP_DMASK_DOT")) : -1;
     if (vd && A->dm_built && A->dm_on && (!DOT || g_dm_mode == 2 || (dm_dot_env >= 0 ? dm_dot_env != 0 : A->nnz >= 40000000))) {
       const unsigned dgrid = (unsigned)A->sell_nslices;
-      /* results of 64 MiB and more leave with non-temporal stores: they do not push x out of the caches while the product still
-         gathers from it (7-point 256^3: 97.9 -> 80.2 us, KSPCG 2759 -> 2805 it/s; 27-point 256^3: 227 -> 205 us; 192^3, 57 MB: no
-         change).  PHIP_SPMV_NT_Y=0|1 overrides. */
-      static const int nty_env = getenv("PHIP_SPMV_NT_Y") ? atoi(getenv("PHIP_SPMV_NT_Y")) : -1;
-      const int        nty = nty_env >= 0 ? nty_env : (A->m >= (8 << 20));
       double        *part = DOT ? A->d_dotpart : NULL;
       if (dm_u_env == 8)
         hipLaunchKernelGGL((spmv_dmask_kernel<DOT, 8>), dim3(dgrid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_rmask, A->d_dmoffs, A->d_dmvals, d_x,
@@ -1162,7 +1168,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
       const int  G = pair_g_env ? pair_g_env : (A->sell_maxlen >= 16 ? 1 : 2);
 #define PAIR_LAUNCH(NTv, Gv)                                                                                                                              \
   hipLaunchKernelGGL((spmv_pair_kernel<NTv, DOT, Gv>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->m, A->sell_nslices, A->d_pptr, A->d_slen, A->d_pgrp, A->d_spoffs, \
-                     A->d_svtab, A->vd_npairs, d_x, d_yin, d_yout, add, d_v, ctl)
+                     A->d_svtab, A->vd_npairs, d_x, d_yin, d_yout, add, d_v, ctl, nty)
       if (pnt) { if (G == 2) PAIR_LAUNCH(true, 2); else PAIR_LAUNCH(true, 1); }
       else { if (G == 2) PAIR_LAUNCH(false, 2); else PAIR_LAUNCH(false, 1); }
 #undef PAIR_LAUNCH

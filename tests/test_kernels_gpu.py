@@ -408,7 +408,7 @@ def test_value_pair_dictionary(ctx, orc):
 
 
 def test_spmv_large_result_nontemporal(ctx, orc):
-    """A product with more than 8 M rows stores its result with non-temporal stores (diagonal-mask kernel): same bits as the oracle,
+    """A product with more than 8 M rows stores its result with non-temporal stores (all three stencil kernels): same bits as the oracle,
     for the plain product, MultAdd and the product with the fused dot (which at this size also goes through the masks)."""
     import ctypes as C
     from petsc_amd import generators as G
@@ -434,6 +434,13 @@ def test_spmv_large_result_nontemporal(ctx, orc):
     ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t), val.ctypes.data_as(C.POINTER(C.c_double))))
     np.testing.assert_array_equal(ctx.to_host(dy, m), yo)
     assert abs(val[0] - x @ yo) <= 1e-12 * np.abs(x * yo).sum()
+    # the same through the pair codes and through streamed values
+    ctx.check(L.phip_mat_set_diag_mask(A, 0))
+    ctx.check(L.phip_mat_mult(A, dx, dy))
+    np.testing.assert_array_equal(ctx.to_host(dy, m), yo)
+    ctx.check(L.phip_mat_set_value_dict(A, 0))
+    ctx.check(L.phip_mat_mult(A, dx, dy))
+    np.testing.assert_array_equal(ctx.to_host(dy, m), yo)
     for p in (dx, dy, dy0):
         ctx.free(p)
     ctx.check(L.phip_mat_destroy(A))
