@@ -531,25 +531,31 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmask_kernel(int32_t m, int
   }
 }
 
-/* second half of the fused dot when the product ran one workgroup per slice: nb partials, summed in a fixed order (thread t adds
-   the entries t, t + 256, ...; then the block tree) and published as reduce_tail publishes */
-__global__ __launch_bounds__(PHIP_THREADS) void dot_partials_kernel(const double *__restrict__ part, int nb, RedCtl c)
+/* second half of the fused dot when the product ran one workgroup per slice: nb partials, summed in a fixed order (thread t of 1024
+   adds the entries t, t + 1024, ...; then the wave trees and the 16 wave sums in order) and published as reduce_tail publishes */
+#define DOTP_THREADS 1024
+__global__ __launch_bounds__(DOTP_THREADS) void dot_partials_kernel(const double *__restrict__ part, int nb, RedCtl c)
 {
-  __shared__ double lds[4];
+  __shared__ double lds[DOTP_THREADS / 64];
   const int t = threadIdx.x;
-  double    a1[1] = {0.0};
+  double    s = 0.0;
   int       i = t;
-  for (; i + 15 * PHIP_THREADS < nb; i += 16 * PHIP_THREADS) { /* sixteen loads in flight, added in index order */
+  for (; i + 15 * DOTP_THREADS < nb; i += 16 * DOTP_THREADS) { /* sixteen loads in flight, added in index order */
     double p[16];
 #pragma unroll
-    for (int u = 0; u < 16; u++) p[u] = part[i + u * PHIP_THREADS];
+    for (int u = 0; u < 16; u++) p[u] = part[i + u * DOTP_THREADS];
 #pragma unroll
-    for (int u = 0; u < 16; u++) a1[0] += p[u];
+    for (int u = 0; u < 16; u++) s += p[u];
   }
-  for (; i < nb; i += PHIP_THREADS) a1[0] += part[i];
-  block_sum<1>(a1, lds);
+  for (; i < nb; i += DOTP_THREADS) s += part[i];
+  s = wave_sum(s);
+  if ((t & 63) == 0) lds[t >> 6] = s;
+  __syncthreads();
   if (t == 0) {
-    const double r = c.accumulate ? c.d_out[c.kofs] + a1[0] : a1[0];
+    double a = 0.0;
+#pragma unroll
+    for (int w = 0; w < DOTP_THREADS / 64; w++) a += lds[w];
+    const double r = c.accumulate ? c.d_out[c.kofs] + a : a;
     c.d_out[c.kofs] = r;
     if (c.h_ll && c.kofs < c.npub) publish_ll(c.h_ll, c.kofs, r, c.seq);
   }
@@ -1161,7 +1167,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
       else
         hipLaunchKernelGGL((spmv_dmask_kernel<DOT, 4>), dim3(dgrid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_rmask, A->d_dmoffs, A->d_dmvals, d_x,
                            d_yin, d_yout, add, d_v, part, ctl, nty);
-      if (DOT) hipLaunchKernelGGL(dot_partials_kernel, dim3(1), dim3(PHIP_THREADS), 0, st, A->d_dotpart, A->sell_nslices, ctl);
+      if (DOT) hipLaunchKernelGGL(dot_partials_kernel, dim3(1), dim3(DOTP_THREADS), 0, st, A->d_dotpart, A->sell_nslices, ctl);
     }
     else if (vd) {
       const bool pnt = 4 * A->pgrp_dwords > PHIP_NT_MATRIX_BYTES;
