@@ -195,6 +195,16 @@ int phip_vec_reduce_local(phip_ctx ctx, int kind, int32_t n, const double *d_x, 
  * phip_comm_allreduce_host.  Raw sums: kind 1 returns sum x^2, not its square root. */
 int phip_vec_reduce_local_host(phip_ctx ctx, int kind, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *h_out);
 int phip_read_scalars(phip_ctx ctx, const double *d_src, int32_t n, double *h_dst);
+/* d_z[k] = sum_i x_i y_k,i, k < nv: phip_vec_reduce_local's kind 0 as an entry point that ALLOCATES NOTHING and needs no context.
+ * It has no counterpart in the reference; it is for callers that cannot call hipMalloc: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid allocation.  The partial sums of the workgroups live in a file-scope __device__ array of the library
+ * (1 MiB + 256 B per GPU, held until the process ends) instead of a context's hipMalloc'ed rows; the kernel is launched on `stream`
+ * (a hipStream_t, NULL = the default stream) of the CURRENT device; inputs and the nv results stay in device memory, nothing is
+ * synchronised.  Limits: 1 <= nv <= 16 per call (PHIP_ERR_ARG_OUTOFRANGE beyond; split longer lists), n >= 0.  Same kernel, grid and
+ * summation order as phip_vec_reduce_local: the same bits.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU
+ * (two streams, two threads) race; calls on one stream, or ordered by events, do not.  The array is left clean by every launch (the
+ * arrival counter returns to 0), so a captured launch may be replayed.  h_dy is a host array of nv device pointers, read before return. */
+int phip_vec_mdot_static(void *stream, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *d_z);
 
 /* ---- by-product reductions --------------------------------------------------------------------------
  * On this hardware a reduction fused into a kernel that streams the operands anyway costs a few microseconds, while a reduction of

@@ -82,6 +82,7 @@ SIGNATURES = [
     ("phip_vec_reduce_begin", C.c_int, [_vp, C.c_int, C.c_int32, _vp, C.c_int32, C.POINTER(_vp), _vp]),
     ("phip_vec_reduce_local_host", C.c_int, [_vp, C.c_int, C.c_int32, _vp, C.c_int32, C.POINTER(_vp), _pD]),
     ("phip_read_scalars", C.c_int, [_vp, _vp, C.c_int32, _pD]),
+    ("phip_vec_mdot_static", C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.POINTER(_vp), _vp]),
     ("phip_comm_create_callbacks", C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.POINTER(_vp)]),
     ("phip_comm_unique_id", C.c_int, [_vp]),
     ("phip_comm_create", C.c_int, [_vp, C.c_char_p, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),

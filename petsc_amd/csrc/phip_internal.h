@@ -68,6 +68,9 @@ int phip_ew_flush(phip_ctx c);
 
 void phip_set_error(const char *fmt, ...);
 
+/* phip_vec.hip: device address of the static partial rows of phip_vec_mdot_static on the current device (looked up once per device) */
+int phip_static_scratch_setup(unsigned long long **ptr);
+
 #define PHIP_CHECK_HIP(call)                                                                       \
   do {                                                                                             \
     hipError_t _e = (call);                                                                        \

@@ -148,3 +148,43 @@ __device__ __forceinline__ void reduce_tail(double (&acc)[NV], double *lds /* un
   /* results of earlier launches of the same call (the first groups of a long VecMDot) ride along: written by earlier kernels of the stream */
   if (c.h_ll && t < c.kofs && t < c.npub) publish_ll(c.h_ll, t, c.d_out[t], c.seq);
 }
+
+/* Tail for launches that must leave nothing behind in their partial rows (phip_vec_mdot_static: the rows are a file-scope __device__
+   array that every call on the GPU shares, and a captured launch may be replayed with the same arguments).  No flags: thread 0 of every
+   workgroup stores its partials write-through, then adds 1 to ONE arrival counter with release/acquire at agent scope; the workgroup
+   whose add returns nb - 1 is the last, sums the rows in the order of reduce_tail's collector (wave w rows w, w+4, ...; lane l the
+   values l, l+64, ...; then the 64-lane tree) -- the same bits -- and puts the counter back to 0 for the next launch.  No workgroup
+   waits for another one.  (MI355X_MICROARCH.md, hand-offs: one lane per workgroup stores sc1 and adds to one unsharded counter, the
+   last arriver loads sc1 after its add returned, the other waves after a workgroup barrier.) */
+template <int NV>
+__device__ __forceinline__ void reduce_tail_counted(double (&acc)[NV], unsigned long long *rows /* [NV][PHIP_RED_BLOCKS][2] */, unsigned int *counter, double *d_out)
+{
+  __shared__ int last;
+  const int      t = threadIdx.x, nb = gridDim.x;
+  if (t == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+      __hip_atomic_store(&rows[2 * ((size_t)k * PHIP_RED_BLOCKS + blockIdx.x)], (unsigned long long)__double_as_longlong(acc[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(nb - 1);
+  }
+  __syncthreads();
+  if (!last) return;
+  const int w = t >> 6, lane = t & 63;
+  for (int k = w; k < NV; k += PHIP_THREADS / 64) {
+    const unsigned long long *row = rows + 2 * ((size_t)k * PHIP_RED_BLOCKS);
+    double                    s = 0.0;
+    for (int j0 = 0; j0 * 64 < nb; j0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int i = lane + 64 * (j0 + j);
+        v[j] = i < nb ? __longlong_as_double((long long)__hip_atomic_load(&row[2 * (size_t)i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) s += v[j];
+    }
+    s = wave_sum(s);
+    if (lane == 0) d_out[k] = s;
+  }
+  if (t == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}

@@ -68,6 +68,10 @@ extern "C" int phip_init(int device, phip_ctx *out)
   PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_flag, sizeof(int) * 16, hipHostMallocDefault));
   PHIP_CHECK_HIP(hipMemsetAsync(c->d_flag, 0, sizeof(int) * 16, c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
+  { /* phip_vec_mdot_static's rows: the symbol look-up happens here, with this device current, not inside a caller's capture */
+    const int rc = phip_static_scratch_setup(NULL);
+    if (rc) return rc;
+  }
   *out = c;
   return 0;
 }

@@ -23,7 +23,8 @@ struct MVPack {
 #include "phip_reduce.h"
 
 /* z[k] = sum_i x_i * y_k,i  for k < NV : x is read once per launch.  partial layout: [k][block] */
-template <int NV>
+/* COUNTED: the tail of phip_vec_mdot_static (reduce_tail_counted): ctl.partial = the static rows, ctl.h_ll = their arrival counter */
+template <int NV, bool COUNTED = false>
 __global__ __launch_bounds__(PHIP_THREADS) void mdot_kernel(int32_t n, const double *__restrict__ x, MVPack P, RedCtl ctl)
 {
   /* many vectors, each read once: non-temporal loads keep them from pushing x out of the caches (192^3: mdot16 165 -> 155 us, mdot8
@@ -51,7 +52,8 @@ __global__ __launch_bounds__(PHIP_THREADS) void mdot_kernel(int32_t n, const dou
     for (int k = 0; k < NV; k++) acc[k] += x[n - 1] * P.y[k][n - 1];
   }
   block_sum<NV>(acc, lds);
-  reduce_tail<NV, 0>(acc, lds, ctl);
+  if (COUNTED) reduce_tail_counted<NV>(acc, ctl.partial, reinterpret_cast<unsigned int *>(ctl.h_ll), ctl.d_out);
+  else reduce_tail<NV, 0>(acc, lds, ctl);
 }
 
 /* kind 1: sum x^2 ; 2: sum |x| ; 3: max |x| with NaN propagation (bvec2.c:253-258) ; 4: {sum |x|, sum x^2} */
@@ -816,5 +818,72 @@ extern "C" int phip_vec_maxpy(phip_ctx c, int32_t n, double *d_x, int32_t nv, co
     k0 += g;
     PHIP_CHECK_HIP(hipGetLastError());
   }
+  return 0;
+}
+
+/* ---- the entry point that allocates nothing (include/petschip.h: phip_vec_mdot_static) -------------------------------------------
+   phip_vec_reduce_local's kind 0 with the partial rows of the reduction in a file-scope __device__ array instead of the context's
+   hipMalloc'ed rows, for callers that cannot allocate and have no context: code under HIP graph capture, serving loops, harnesses that
+   forbid hipMalloc.  Same kernel, same grid, same order of the sums: the bits of phip_vec_reduce_local.
+   `scratch` is a host-side stand-in in host code, not a device address: hipGetSymbolAddress gives each GPU's own copy, once per device. */
+#define PHIP_STATIC_NV MV_MAX
+#define PHIP_STATIC_WORDS (2 * (size_t)PHIP_STATIC_NV * PHIP_RED_BLOCKS) /* 1 MiB of partial rows ... */
+static __device__ __align__(256) unsigned long long scratch[PHIP_STATIC_WORDS + 32]; /* ... + one 256-byte line for the arrival counter */
+
+#include <mutex>
+#define PHIP_STATIC_MAXDEV 64
+static unsigned long long *g_scratch_ptr[PHIP_STATIC_MAXDEV];
+static std::mutex          g_scratch_mutex;
+
+/* once per device, with that device current (phip_init calls it; phip_vec_mdot_static calls it on a device that never saw phip_init) */
+int phip_static_scratch_setup(unsigned long long **ptr)
+{
+  int dev = -1;
+  PHIP_CHECK_HIP(hipGetDevice(&dev));
+  PHIP_REQUIRE(dev >= 0 && dev < PHIP_STATIC_MAXDEV, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_mdot_static: device %d (the table holds %d)", dev, PHIP_STATIC_MAXDEV);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void *p = NULL;
+    PHIP_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    PHIP_REQUIRE(p, PHIP_ERR_LIB, "phip_vec_mdot_static: hipGetSymbolAddress returned no address on device %d", dev);
+    g_scratch_ptr[dev] = (unsigned long long *)p; /* the array is zero-initialised by the loader: the arrival counter starts at 0 */
+  }
+  if (ptr) *ptr = g_scratch_ptr[dev];
+  return 0;
+}
+
+template <int NV>
+static void launch_mdot_static(hipStream_t st, int32_t n, const double *d_x, const MVPack &P, const RedCtl &ctl, int grid)
+{
+  hipLaunchKernelGGL((mdot_kernel<NV, true>), dim3(grid), dim3(PHIP_THREADS), 0, st, n, d_x, P, ctl);
+}
+
+extern "C" int phip_vec_mdot_static(void *stream, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *d_z)
+{
+  CHECK_N(n, "phip_vec_mdot_static");
+  PHIP_REQUIRE(nv >= 1 && nv <= PHIP_STATIC_NV, PHIP_ERR_ARG_OUTOFRANGE,
+               "phip_vec_mdot_static: nv=%d, this entry point takes 1..%d vectors per call (its partial rows are a fixed %zu-byte device array); split the list or use phip_vec_reduce_local",
+               nv, PHIP_STATIC_NV, sizeof(unsigned long long) * PHIP_STATIC_WORDS);
+  PHIP_REQUIRE(h_dy && d_z && (d_x || !n), PHIP_ERR_ARG_NULL, "phip_vec_mdot_static: null argument");
+  unsigned long long *ptr = NULL;
+  int                 rc = phip_static_scratch_setup(&ptr);
+  if (rc) return rc;
+  const int grid = reduce_grid(n); /* <= PHIP_RED_GRID <= PHIP_RED_BLOCKS: the rows hold one partial per workgroup */
+  MVPack    P;
+  for (int k = 0; k < MV_MAX; k++) { P.y[k] = (k < nv) ? h_dy[k] : d_x; P.a[k] = 0.0; }
+  RedCtl ctl;
+  memset(&ctl, 0, sizeof(ctl));
+  ctl.partial = ptr;                      /* the device address, never the array's name */
+  ctl.h_ll = ptr + PHIP_STATIC_WORDS;     /* the arrival counter: 0 between launches (the last workgroup puts it back) */
+  ctl.d_out = d_z;
+  const hipStream_t st = (hipStream_t)stream;
+  switch (nv) {
+#define MDOT_CASE(N) case N: launch_mdot_static<N>(st, n, d_x, P, ctl, grid); break;
+    MDOT_CASE(1) MDOT_CASE(2) MDOT_CASE(3) MDOT_CASE(4) MDOT_CASE(5) MDOT_CASE(6) MDOT_CASE(7) MDOT_CASE(8)
+    MDOT_CASE(9) MDOT_CASE(10) MDOT_CASE(11) MDOT_CASE(12) MDOT_CASE(13) MDOT_CASE(14) MDOT_CASE(15)
+#undef MDOT_CASE
+  default: launch_mdot_static<16>(st, n, d_x, P, ctl, grid); break;
+  }
+  PHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
