@@ -22,6 +22,18 @@
 #include <../src/mat/impls/aij/mpi/mpiaij.h>
 #include "petschip.h"
 
+/* libpetschip's PetscInt is int32_t and its PetscScalar is double (include/petschip.h "Conventions"): refuse any other configuration */
+typedef char petschip_needs_32bit_PetscInt[(sizeof(PetscInt) == sizeof(int32_t)) ? 1 : -1];
+typedef char petschip_needs_double_PetscScalar[(sizeof(PetscScalar) == sizeof(double)) ? 1 : -1];
+typedef char petschip_needs_int_PetscMPIInt[(sizeof(PetscMPIInt) == sizeof(int32_t)) ? 1 : -1];
+
+/* This file is written to work OUT OF TREE (a shared library opened by -dll_append): it calls only PETSC_EXTERN symbols of libpetsc.
+   The routines a subtype normally chains to (VecDestroy_Seq, VecCreate_MPI_Private, MatDestroy_SeqAIJ, MatAssemblyEnd_MPIAIJ, ...) are
+   PETSC_INTERN (hidden visibility, src/vec/vec/impls/dvecimpl.h:27-56, src/mat/impls/aij/seq/aij.h:295-314) or file-static
+   (VecPlaceArray_MPI, pbvec.c:39), so the constructors below run the PUBLIC base constructor (VecCreate_Seq / VecCreate_MPI /
+   MatCreate_SeqAIJ / MatCreate_MPIAIJ), keep a copy of the ops table it filled, and chain through those saved pointers. */
+PETSC_EXTERN PetscErrorCode VecCreate_MPI(Vec);   /* src/vec/vec/impls/mpi/pbvec.c; declared like this by vecregall.c:6 */
+
 #define VECSEQHIP    "seqhip"
 #define VECMPIHIP    "mpihip"
 #define VECHIP       "hip"
@@ -34,6 +46,7 @@
 /* ---- one context and one communicator per process ------------------------------------------------------------ */
 static phip_ctx  hipctx  = NULL;
 static phip_comm hipcomm = NULL; /* mirrors PETSC_COMM_WORLD: one rank per GPU */
+static PetscBool hipsync = PETSC_FALSE; /* -vec_hip_sync: wait for the device after every operation (role of -cusp_synchronize, src/sys/objects/init.c:674-676) */
 
 static PetscErrorCode PetscHIPFinalize(void)
 {
@@ -54,9 +67,14 @@ static PetscErrorCode PetscHIPInitialize(void)
   if (hipctx) PetscFunctionReturn(0);
   ierr = MPI_Comm_rank(PETSC_COMM_WORLD,&rank);CHKERRQ(ierr);
   ierr = MPI_Comm_size(PETSC_COMM_WORLD,&size);CHKERRQ(ierr);
+#if defined(PETSC_HAVE_MPIUNI) || !defined(MPI_COMM_TYPE_SHARED)
+  lrank = 0; node = MPI_COMM_NULL; (void)node;                   /* one process (MPIUNI has no MPI_Comm_split_type), or an MPI-2 library: device 0 */
+  if (size > 1) SETERRQ(PETSC_COMM_WORLD,PETSC_ERR_SUP,"the HIP types need MPI_Comm_split_type (MPI-3) to give every rank of a node its own GPU");
+#else
   ierr = MPI_Comm_split_type(PETSC_COMM_WORLD,MPI_COMM_TYPE_SHARED,rank,MPI_INFO_NULL,&node);CHKERRQ(ierr);
   ierr = MPI_Comm_rank(node,&lrank);CHKERRQ(ierr);
   ierr = MPI_Comm_free(&node);CHKERRQ(ierr);
+#endif
   CHKERRPHIP(phip_init((int)lrank,&hipctx));                     /* one rank per GPU of the node */
   if (size == 1) CHKERRPHIP(phip_comm_create(hipctx,"self",NULL,1,0,&hipcomm));
   else {
@@ -64,6 +82,7 @@ static PetscErrorCode PetscHIPInitialize(void)
     ierr = MPI_Bcast(id,128,MPI_BYTE,0,PETSC_COMM_WORLD);CHKERRQ(ierr);
     CHKERRPHIP(phip_comm_create(hipctx,"rccl",id,size,rank,&hipcomm));
   }
+  ierr = PetscOptionsGetBool(NULL,"-vec_hip_sync",&hipsync,NULL);CHKERRQ(ierr);
   ierr = PetscRegisterFinalize(PetscHIPFinalize);CHKERRQ(ierr);
   PetscFunctionReturn(0);
 }
@@ -82,7 +101,7 @@ typedef struct {
 } VecHIPByProduct;
 
 /* v->data: MUST begin with the layout of Vec_Seq / Vec_MPI (VECHEADER first, vecimpl.h:175-178) because inherited host ops cast it */
-typedef struct { Vec_MPI mpi; double *d; VecHIPValid valid; PetscBool ismpi; VecHIPByProduct bp; } Vec_HIP;
+typedef struct { Vec_MPI mpi; double *d; VecHIPValid valid; PetscBool ismpi; VecHIPByProduct bp; struct _VecOps base; /* the Seq/MPI table the base constructor filled */ } Vec_HIP;
 #define VHIP(v) ((Vec_HIP*)(v)->data)
 
 static PetscErrorCode VecHIPSyncToGPU(Vec v)       /* role of VecCUSPCopyToGPU veccusp.cu:90 */
@@ -108,6 +127,7 @@ PetscErrorCode VecHIPRestoreArrayWrite(Vec v,PetscScalar **a)   /* device copy i
   PetscErrorCode ierr;
   PetscFunctionBegin;
   VHIP(v)->valid = VHIP_GPU; *a = NULL;
+  if (hipsync) CHKERRPHIP(phip_sync(hipctx));                    /* WaitForGPU, cuspvecimpl.h:66 */
   ierr = PetscObjectStateIncrease((PetscObject)v);CHKERRQ(ierr);
   PetscFunctionReturn(0);
 }
@@ -378,7 +398,7 @@ static PetscErrorCode VecPlaceArray_HIP(Vec v,const PetscScalar *a)
   PetscErrorCode ierr;
   PetscFunctionBegin;
   ierr = VecHIPSyncToCPU(v);CHKERRQ(ierr);
-  if (VHIP(v)->ismpi) { ierr = VecPlaceArray_MPI(v,a);CHKERRQ(ierr); } else { ierr = VecPlaceArray_Seq(v,a);CHKERRQ(ierr); }
+  ierr = (*VHIP(v)->base.placearray)(v,a);CHKERRQ(ierr);         /* VecPlaceArray_Seq bvec2.c:687 / VecPlaceArray_MPI pbvec.c:39 */
   VHIP(v)->valid = VHIP_CPU;
   PetscFunctionReturn(0);
 }
@@ -387,7 +407,7 @@ static PetscErrorCode VecResetArray_HIP(Vec v)
   PetscErrorCode ierr;
   PetscFunctionBegin;
   ierr = VecHIPSyncToCPU(v);CHKERRQ(ierr);
-  if (VHIP(v)->ismpi) { ierr = VecResetArray_MPI(v);CHKERRQ(ierr); } else { ierr = VecResetArray_Seq(v);CHKERRQ(ierr); }
+  ierr = (*VHIP(v)->base.resetarray)(v);CHKERRQ(ierr);
   VHIP(v)->valid = VHIP_CPU;
   PetscFunctionReturn(0);
 }
@@ -396,8 +416,8 @@ static PetscErrorCode VecReplaceArray_HIP(Vec v,const PetscScalar *a)
   PetscErrorCode ierr;
   PetscFunctionBegin;
   ierr = VecHIPSyncToCPU(v);CHKERRQ(ierr);
-  if (VHIP(v)->ismpi) SETERRQ(PETSC_COMM_SELF,PETSC_ERR_SUP,"VecReplaceArray on VECMPIHIP"); /* Vec_MPI has no replacearray either (pbvec.c:101-171) */
-  ierr = VecReplaceArray_Seq(v,a);CHKERRQ(ierr);
+  if (!VHIP(v)->base.replacearray) SETERRQ(PETSC_COMM_SELF,PETSC_ERR_SUP,"VecReplaceArray on VECMPIHIP"); /* Vec_MPI has no replacearray either (pbvec.c:101-171) */
+  ierr = (*VHIP(v)->base.replacearray)(v,a);CHKERRQ(ierr);
   VHIP(v)->valid = VHIP_CPU;
   PetscFunctionReturn(0);
 }
@@ -409,7 +429,7 @@ static PetscErrorCode VecDestroy_HIP(Vec v)
   PetscFunctionBegin;
   if (h->d) CHKERRPHIP(phip_free(hipctx,h->d));
   h->d = NULL;
-  if (h->ismpi) { ierr = VecDestroy_MPI(v);CHKERRQ(ierr); } else { ierr = VecDestroy_Seq(v);CHKERRQ(ierr); }
+  ierr = (*h->base.destroy)(v);CHKERRQ(ierr);                    /* VecDestroy_Seq bvec2.c:739 / VecDestroy_MPI pdvec.c:11: frees the host array and v->data */
   PetscFunctionReturn(0);
 }
 static PetscErrorCode VecDuplicate_HIP(Vec win,Vec *V)      /* keeps KSPCreateVecs -> VecDuplicateVecs (iterativ.c:993) on the device */
@@ -429,19 +449,18 @@ static PetscErrorCode VecCreate_HIP_Private(Vec V,PetscBool ismpi,const char *ty
 {
   PetscErrorCode ierr;
   Vec_HIP       *h;
-  PetscScalar   *host;
   PetscFunctionBegin;
   ierr = PetscHIPInitialize();CHKERRQ(ierr);
-  ierr = PetscLayoutSetUp(V->map);CHKERRQ(ierr);
-  ierr = PetscCalloc1(V->map->n,&host);CHKERRQ(ierr);
-  if (ismpi) { ierr = VecCreate_MPI_Private(V,PETSC_FALSE,0,host);CHKERRQ(ierr); }    /* pbvec.c:183 */
-  else       { ierr = VecCreate_Seq_Private(V,host);CHKERRQ(ierr); }                  /* bvec2.c:873 */
+  /* the public base constructor: layout, zeroed host array, Seq/MPI ops table (bvec3.c:VecCreate_Seq -> VecCreate_Seq_Private bvec2.c:873;
+     pbvec.c:VecCreate_MPI -> VecCreate_MPI_Private pbvec.c:183) */
+  if (ismpi) { ierr = VecCreate_MPI(V);CHKERRQ(ierr); } else { ierr = VecCreate_Seq(V);CHKERRQ(ierr); }
   /* grow the data struct: Vec_Seq / Vec_MPI both start with VECHEADER, Vec_HIP embeds the larger one */
   ierr = PetscNewLog(V,&h);CHKERRQ(ierr);
   ierr = PetscMemcpy(&h->mpi,V->data,ismpi ? sizeof(Vec_MPI) : sizeof(Vec_Seq));CHKERRQ(ierr);
   ierr = PetscFree(V->data);CHKERRQ(ierr);
   V->data = (void*)h;
-  h->mpi.array_allocated = host; h->ismpi = ismpi; h->valid = VHIP_BOTH;
+  ierr = PetscMemcpy(&h->base,V->ops,sizeof(struct _VecOps));CHKERRQ(ierr);
+  h->ismpi = ismpi; h->valid = VHIP_BOTH;
   CHKERRPHIP(phip_malloc(hipctx,sizeof(PetscScalar)*V->map->n,(void**)&h->d));
   CHKERRPHIP(phip_vec_set(hipctx,V->map->n,h->d,0.0));
   V->petscnative = PETSC_FALSE;                                   /* host array accessors go through the ops below */
@@ -479,8 +498,13 @@ PETSC_EXTERN PetscErrorCode VecCreate_HIP(Vec V)            /* mpicusp.cu:237-25
 }
 
 /* ---- Mat ----------------------------------------------------------------------------------------------------- */
-typedef struct { phip_mat dev,tdev; PetscObjectState state,nonzerostate; } Mat_SeqAIJHIP;          /* B->spptr of the Seq type */
-typedef struct { phip_halo halo; PetscObjectState nonzerostate; } Mat_MPIAIJHIP;              /* Mat_MPIAIJ.spptr (mpiaij.h:77) */
+typedef PetscErrorCode (*MatAssemblyEndFn)(Mat,MatAssemblyType);
+typedef PetscErrorCode (*MatDestroyFn)(Mat);
+typedef enum {MAT_HIP_AUTO=0,MAT_HIP_CSR=1,MAT_HIP_SELL=2} MatHIPStorageFormat;   /* phip_mat_set_format; precedent MatCUSPStorageFormat, petscmat.h */
+static const char *const MatHIPStorageFormats[] = {"AUTO","CSR","SELL","MatHIPStorageFormat","MAT_HIP_",0};
+typedef struct { phip_mat dev,tdev; PetscObjectState state,nonzerostate; MatAssemblyEndFn base_assemblyend; MatDestroyFn base_destroy;
+                 MatHIPStorageFormat format; PetscBool valuedict,diagmask,hotcolumns,optset; } Mat_SeqAIJHIP; /* B->spptr of the Seq type */
+typedef struct { phip_halo halo; PetscObjectState nonzerostate; MatAssemblyEndFn base_assemblyend; MatDestroyFn base_destroy; } Mat_MPIAIJHIP;      /* Mat_MPIAIJ.spptr (mpiaij.h:77) */
 
 static PetscErrorCode MatHIPCopyToGPU(Mat A)                /* role of MatCUSPCopyToGPU aijcusp.cu:110-208 */
 {
@@ -498,8 +522,32 @@ static PetscErrorCode MatHIPCopyToGPU(Mat A)                /* role of MatCUSPCo
     CHKERRPHIP(phip_mat_create(hipctx,A->rmap->n,A->cmap->n,a->i,a->j,a->a,a->compressedrow.use,a->compressedrow.nrows,
                                a->compressedrow.i,a->compressedrow.rindex,&h->dev));
     h->nonzerostate = A->nonzerostate;
+    if (h->optset) {                                             /* -mat_hip_* (MatSetFromOptions_SeqAIJHIP) */
+      if (h->format != MAT_HIP_AUTO) CHKERRPHIP(phip_mat_set_format(h->dev,(int)h->format));
+      CHKERRPHIP(phip_mat_set_value_dict(h->dev,(int)h->valuedict));
+      CHKERRPHIP(phip_mat_set_diag_mask(h->dev,(int)h->diagmask));
+      CHKERRPHIP(phip_mat_set_hot_columns(h->dev,(int)h->hotcolumns));
+    }
   }
   h->state = st;
+  PetscFunctionReturn(0);
+}
+/* -mat_hip_storage_format auto|csr|sell, -mat_hip_value_dict, -mat_hip_diag_mask, -mat_hip_hot_columns: which of the device layouts of
+   include/petschip.h the products may use (all give the same bits).  Precedent: MatSetFromOptions_SeqAIJCUSP, aijcusp.cu:82-105. */
+static PetscErrorCode MatSetFromOptions_SeqAIJHIP(PetscOptions *PetscOptionsObject,Mat A)
+{
+  Mat_SeqAIJHIP *h = (Mat_SeqAIJHIP*)A->spptr;
+  PetscErrorCode ierr;
+  PetscBool      f0,f1,f2,f3;
+  PetscFunctionBegin;
+  ierr = PetscOptionsHead(PetscOptionsObject,"SeqAIJHIP options");CHKERRQ(ierr);
+  ierr = PetscOptionsEnum("-mat_hip_storage_format","device layout of the SpMV: CSR row blocks, or the sliced layout of stencil matrices","phip_mat_set_format",
+                          MatHIPStorageFormats,(PetscEnum)h->format,(PetscEnum*)&h->format,&f0);CHKERRQ(ierr);
+  ierr = PetscOptionsBool("-mat_hip_value_dict","name (diagonal, value) pairs by one byte when the matrix holds <= 256 of them","phip_mat_set_value_dict",h->valuedict,&h->valuedict,&f1);CHKERRQ(ierr);
+  ierr = PetscOptionsBool("-mat_hip_diag_mask","hold a row as a 32-bit set of pairs when there are <= 32","phip_mat_set_diag_mask",h->diagmask,&h->diagmask,&f2);CHKERRQ(ierr);
+  ierr = PetscOptionsBool("-mat_hip_hot_columns","gather x in descending order of column use (power-law matrices)","phip_mat_set_hot_columns",h->hotcolumns,&h->hotcolumns,&f3);CHKERRQ(ierr);
+  ierr = PetscOptionsTail();CHKERRQ(ierr);
+  if (f0 || f1 || f2 || f3) h->optset = PETSC_TRUE;
   PetscFunctionReturn(0);
 }
 static PetscErrorCode MatMult_SeqAIJHIP(Mat A,Vec xx,Vec yy)  /* aij.c:1272-1327 */
@@ -579,7 +627,7 @@ static PetscErrorCode MatAssemblyEnd_SeqAIJHIP(Mat A,MatAssemblyType mode)   /* 
 {
   PetscErrorCode ierr;
   PetscFunctionBegin;
-  ierr = MatAssemblyEnd_SeqAIJ(A,mode);CHKERRQ(ierr);
+  ierr = (*((Mat_SeqAIJHIP*)A->spptr)->base_assemblyend)(A,mode);CHKERRQ(ierr);   /* MatAssemblyEnd_SeqAIJ aij.c:968-1024 */
   if (mode == MAT_FLUSH_ASSEMBLY) PetscFunctionReturn(0);
   ierr = MatHIPCopyToGPU(A);CHKERRQ(ierr);
   PetscFunctionReturn(0);
@@ -604,11 +652,11 @@ static PetscErrorCode MatCreateVecs_AIJHIP(Mat mat,Vec *right,Vec *left)     /* 
 }
 static PetscErrorCode MatDestroy_SeqAIJHIP(Mat A)            /* aijcusp.cu:529-557 */
 {
-  PetscErrorCode ierr; Mat_SeqAIJHIP *h = (Mat_SeqAIJHIP*)A->spptr;
+  PetscErrorCode ierr; Mat_SeqAIJHIP *h = (Mat_SeqAIJHIP*)A->spptr; MatDestroyFn base = h->base_destroy;
   PetscFunctionBegin;
-  if (h && h->dev) CHKERRPHIP(phip_mat_destroy(h->dev));
+  if (h->dev) CHKERRPHIP(phip_mat_destroy(h->dev));
   ierr = PetscFree(A->spptr);CHKERRQ(ierr);                  /* allocated with PetscNew, so MatDestroy's own PetscFree would also be fine */
-  ierr = MatDestroy_SeqAIJ(A);CHKERRQ(ierr);
+  ierr = (*base)(A);CHKERRQ(ierr);                           /* MatDestroy_SeqAIJ aij.c:1030 */
   PetscFunctionReturn(0);
 }
 PETSC_EXTERN PetscErrorCode MatCreate_SeqAIJHIP(Mat B)
@@ -620,6 +668,9 @@ PETSC_EXTERN PetscErrorCode MatCreate_SeqAIJHIP(Mat B)
   ((Mat_SeqAIJ*)B->data)->inode.use = PETSC_FALSE;                           /* aijcusp.cu:573 */
   ierr = PetscNewLog(B,&h);CHKERRQ(ierr);
   B->spptr = h;
+  h->base_assemblyend = B->ops->assemblyend; h->base_destroy = B->ops->destroy;
+  h->format = MAT_HIP_AUTO; h->valuedict = h->diagmask = h->hotcolumns = PETSC_TRUE; h->optset = PETSC_FALSE;
+  B->ops->setfromoptions = MatSetFromOptions_SeqAIJHIP;
   B->ops->mult = MatMult_SeqAIJHIP;               B->ops->multadd = MatMultAdd_SeqAIJHIP;
   B->ops->getdiagonal = MatGetDiagonal_SeqAIJHIP; B->ops->assemblyend = MatAssemblyEnd_SeqAIJHIP;
   B->ops->destroy = MatDestroy_SeqAIJHIP;         B->ops->getvecs = MatCreateVecs_AIJHIP;
@@ -656,7 +707,7 @@ static PetscErrorCode MatAssemblyEnd_MPIAIJHIP(Mat A,MatAssemblyType mode)
 {
   Mat_MPIAIJ    *a = (Mat_MPIAIJ*)A->data; Mat_MPIAIJHIP *h = (Mat_MPIAIJHIP*)a->spptr; PetscErrorCode ierr;
   PetscFunctionBegin;
-  ierr = MatAssemblyEnd_MPIAIJ(A,mode);CHKERRQ(ierr);                          /* mpiaij.c:703-773: stash, A, MatSetUpMultiply, B */
+  ierr = (*h->base_assemblyend)(A,mode);CHKERRQ(ierr);                         /* MatAssemblyEnd_MPIAIJ mpiaij.c:703-773: stash, A, MatSetUpMultiply, B */
   if (mode == MAT_FLUSH_ASSEMBLY) PetscFunctionReturn(0);
   if (!h->halo || h->nonzerostate != A->nonzerostate) {
     /* harvest the plan the core just built (VecScatter_MPI_General, vecimpl.h:245-273; neighbours ascending, receives contiguous) */
@@ -726,11 +777,11 @@ static PetscErrorCode MatMultTransposeAdd_MPIAIJHIP(Mat A,Vec xx,Vec yy,Vec zz)
 static PetscErrorCode MatMultTranspose_MPIAIJHIP(Mat A,Vec xx,Vec yy) { return MatMultTransposeAdd_MPIAIJHIP(A,xx,NULL,yy); }
 static PetscErrorCode MatDestroy_MPIAIJHIP(Mat A)
 {
-  Mat_MPIAIJ *a = (Mat_MPIAIJ*)A->data; Mat_MPIAIJHIP *h = (Mat_MPIAIJHIP*)a->spptr; PetscErrorCode ierr;
+  Mat_MPIAIJ *a = (Mat_MPIAIJ*)A->data; Mat_MPIAIJHIP *h = (Mat_MPIAIJHIP*)a->spptr; PetscErrorCode ierr; MatDestroyFn base = h->base_destroy;
   PetscFunctionBegin;
-  if (h && h->halo) CHKERRPHIP(phip_halo_destroy(h->halo));
+  if (h->halo) CHKERRPHIP(phip_halo_destroy(h->halo));
   ierr = PetscFree(a->spptr);CHKERRQ(ierr);
-  ierr = MatDestroy_MPIAIJ(A);CHKERRQ(ierr);
+  ierr = (*base)(A);CHKERRQ(ierr);                           /* MatDestroy_MPIAIJ mpiaij.c:1158 */
   PetscFunctionReturn(0);
 }
 PETSC_EXTERN PetscErrorCode MatCreate_MPIAIJHIP(Mat B)       /* mpiaijcusp.cu:196-226 */
@@ -742,6 +793,7 @@ PETSC_EXTERN PetscErrorCode MatCreate_MPIAIJHIP(Mat B)       /* mpiaijcusp.cu:19
   a = (Mat_MPIAIJ*)B->data;
   ierr = PetscNewLog(B,&h);CHKERRQ(ierr);
   a->spptr = h;
+  h->base_assemblyend = B->ops->assemblyend; h->base_destroy = B->ops->destroy;
   ierr = PetscObjectComposeFunction((PetscObject)B,"MatMPIAIJSetPreallocation_C",MatMPIAIJSetPreallocation_MPIAIJHIP);CHKERRQ(ierr);
   B->ops->mult = MatMult_MPIAIJHIP;  B->ops->assemblyend = MatAssemblyEnd_MPIAIJHIP;
   B->ops->getvecs = MatCreateVecs_AIJHIP; B->ops->destroy = MatDestroy_MPIAIJHIP;
@@ -765,3 +817,6 @@ PETSC_EXTERN PetscErrorCode PetscDLLibraryRegister_petschip_glue(void)
   ierr = MatRegister(MATMPIAIJHIP,MatCreate_MPIAIJHIP);CHKERRQ(ierr);
   PetscFunctionReturn(0);
 }
+/* the loader derives the symbol from the file name (dl.c:175-191: lib<basename>.so -> PetscDLLibraryRegister_<basename>): the same
+   registration for a library that was linked together with the kernels and installed as libpetschip.so */
+PETSC_EXTERN PetscErrorCode PetscDLLibraryRegister_petschip(void) { return PetscDLLibraryRegister_petschip_glue(); }
