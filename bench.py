@@ -1,28 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- the judged benchmark of the sparse-solve hot path (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload lap7_128|box27_256|lap7_<n>|box27_<n>]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload box27_256|lap7_128|lap7_<n>|box27_<n>] [--scaling strong|weak]
+                    [--legs auto|none|name,name] [--no-cpu-baseline]
 
 A "step" is one KSPCG + PCJACOBI iteration through MATAIJHIP / VECHIP (cg.c:180-275: MatMult, 2 VecTDot, VecNorm, 2 VecAXPY,
 VecAYPX, PCApply), i.e. one pass of the whole hot path.  The K timed steps are ONE KSPSolve capped at K iterations (rtol 0), so
 the timed region also contains KSPSolve's set-up (VecSet, VecCopy, one PCApply, VecNorm, VecTDot): extra work, never less.
 
-Default workload = BASELINE.json configs[1]: 3-D 7-point Laplacian 128^3 per GPU (N > 1: weak scaling, the global grid is
-128 x 128 x 128N cut into z-slabs by MPIAIJ's row-ownership rule; ghost exchange and reductions over RCCL).
+Default workload, at every N: BASELINE.json configs[2], the north star -- KSPCG+PCJACOBI on the 3-D 27-point 256^3 problem, STRONG
+scaling: the same global matrix cut into MPIAIJ row blocks (z-slabs), ghost exchange and reductions between the ranks.  It fits one
+GPU, so N = 1 runs it too and value(N) / value(1) is the strong-scaling speed-up the >= 6x target is quoted on.
 
-value   = whole-job algorithmic HBM bytes of the K iterations / wall time (GB/s): per rank and iteration
-          SpMV 12 nz + 20 m + 4 (+ the off-diagonal block's MultAdd 12 nzB + 28 mB on N > 1) + 136 m of vector kernels
-          (SURVEY.md 8d).  iterations/s and the SpMV-only figures ride along in the same JSON line.
-roofline = the SpMV kernel (spmv_sell_kernel for stencil matrices, else spmv_rowblock_kernel): 200 launches back to back between two hipEvents on the library's compute
-          stream.  (Each launch inside the timed CG region is also bracketed by an event pair, phip_profile_*; that figure
-          carries ~3 us of event overhead per launch and is reported beside it, not as the roofline.)
-cpu_baseline = the oracle (C restatement of the reference loops, -O3 -march=native, ONE core = MATSEQAIJ) on the same matrix,
-          a bounded number of CG iterations, on rank 0 at N = 1 only.
+value    = whole-job ALGORITHMIC bytes of the K iterations / wall time (GB/s): per rank and iteration SpMV 12 nz + 20 m + 4 (+ the
+           off-diagonal block's MultAdd 12 nzB + 28 mB on N > 1) + 136 m of vector kernels.  KSPCG iterations/s ride along.
+roofline = the kernel with the largest share of the timed iteration, priced on the bytes it REALLY moves in its device layout (never
+           more than the algorithmic CSR bytes) over its average launch time: frac <= 1 by construction.  The algorithmic figure
+           (12 nz + 20 m + 4 over the same time) is reported beside it as effective_GBps.  Every other kernel of the iteration and
+           every leg carries an object of the same shape under "kernels" / "legs".
+legs     (N = 1, rank 0): the other single-GPU measurements the metric names --
+           lap7_128      BASELINE configs[1]: 7-point 128^3 SpMV (the >= 70 % target) + KSPCG it/s; the working set fits the 256 MiB
+                         Infinity Cache, which the leg says
+           lap7_256_var  7-point 256^3 with per-entry perturbed values (what a variable-coefficient / FEM assembly gives): no value
+                         dictionary applies, the matrix streams 9 B/nz (SELL-dict) from HBM, 1.5 GB per launch, far outside the caches
+           lap7_256_csr  the same matrix through the general CSR row-block kernel (12 B/nz, any matrix)
+cpu_baseline = the oracle (C restatement of the reference loops, -O3 -march=native) on the same system: 16 row blocks / threads as
+           MATMPIAIJ would run it on the host's CPU share, and one core (MATSEQAIJ); rank 0 at N = 1 only, bounded sample.
+Timing: hipEvents on the library's compute stream.  avg = K launches back to back between two events (best of 3); p10/p50/p90 = the
+same launches bracketed one by one (each figure then carries the event pair's own ~2-3 us).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,7 +42,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec; ~6.3 TB/s is what a streaming copy achieves
+REPS = 200
 
 
 def parse_workload(name):
@@ -42,18 +54,203 @@ def parse_workload(name):
     return kind, n
 
 
-def local_rows(kind, n, size, rank, scaling):
-    """CSR of this rank's rows (global sorted columns).  weak: n x n x (n*size) grid, one n^3 slab per rank."""
+def local_rows(kind, n, size, rank, scaling, perturb=False):
+    """CSR of this rank's rows (global sorted columns).  strong: n^3 grid; weak: n x n x (n*size) grid, one n^3 slab per rank."""
     from petsc_amd import generators as G
     nzdim = n * size if scaling == "weak" else n
     N = n * n * nzdim
     m = N // size + (1 if (N % size) > rank else 0)
     rs = sum(N // size + (1 if (N % size) > r else 0) for r in range(rank))
-    if kind == "lap7":
-        ai, aj, aa = G.laplace3d_7pt(n, n, nzdim, rstart=rs, rend=rs + m, dirichlet_rows=False)
-    else:
-        ai, aj, aa = G.box3d_27pt(n, n, nzdim, rstart=rs, rend=rs + m)
+    # = G.laplace3d_7pt(..., dirichlet_rows=False) / G.box3d_27pt(...), built by the C loop of the host library (tests/test_host_cpu.py)
+    ai, aj, aa = G.stencil_rows_native(7 if kind == "lap7" else 27, n, n, nzdim, rs, rs + m)
+    if perturb:  # every stored entry gets a value of its own (relative change <= 1e-3): nothing for a value dictionary to find
+        k = np.arange(int(ai[0]), int(ai[0]) + len(aa), dtype=np.uint64)
+        k = (k * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)
+        aa = aa * (1.0 + 1e-3 * (k.astype(np.float64) / float(1 << 24) - 0.5))
     return N, m, rs, ai, aj, aa
+
+
+def pct(v, q):
+    return float(np.percentile(np.asarray(v, dtype=np.float64), q))
+
+
+class Timer:
+    """hipEvent timing on the library's compute stream (phip_event_*)."""
+
+    def __init__(self, L, ctx):
+        self.L, self.ctx = L, ctx
+
+    def _ev(self):
+        e = C.c_void_p()
+        rc = self.L.phip_event_create(self.ctx, C.byref(e))
+        assert rc == 0, self.L.phip_last_error()
+        return e
+
+    def region(self, fn, reps):
+        e0, e1 = self._ev(), self._ev()
+        self.L.phip_event_record(self.ctx, e0)
+        for _ in range(reps):
+            fn()
+        self.L.phip_event_record(self.ctx, e1)
+        ms = C.c_float()
+        rc = self.L.phip_event_elapsed_ms(self.ctx, e0, e1, C.byref(ms))
+        assert rc == 0, self.L.phip_last_error()
+        self.L.phip_event_destroy(self.ctx, e0); self.L.phip_event_destroy(self.ctx, e1)
+        return ms.value / reps
+
+    def each(self, fn, reps):
+        ev = [self._ev() for _ in range(reps + 1)]
+        for i in range(reps):
+            self.L.phip_event_record(self.ctx, ev[i])
+            fn()
+        self.L.phip_event_record(self.ctx, ev[reps])
+        out, ms = [], C.c_float()
+        self.L.phip_event_elapsed_ms(self.ctx, ev[0], ev[reps], C.byref(ms))  # synchronises on the last event
+        for i in range(reps):
+            self.L.phip_event_elapsed_ms(self.ctx, ev[i], ev[i + 1], C.byref(ms))
+            out.append(ms.value)
+        for e in ev:
+            self.L.phip_event_destroy(self.ctx, e)
+        return out
+
+    def kernel(self, fn, reps=REPS, warm=20):
+        """-> (avg_us back to back, [p10, p50, p90] us of individually bracketed launches)"""
+        for _ in range(warm):
+            fn()
+        self.L.phip_sync(self.ctx)
+        avg = min(self.region(fn, reps) for _ in range(3)) * 1e3
+        d = self.each(fn, reps)
+        return avg, [round(pct(d, q) * 1e3, 2) for q in (10, 50, 90)]
+
+
+def layout_of(L, hA, m, n, nz):
+    """(kernel name, layout text, bytes one launch really moves, algorithmic CSR bytes) of the device layout the library chose."""
+    f_, nd_, pad_ = C.c_int(), C.c_int32(), C.c_int64()
+    L.phip_mat_format_info(hA, C.byref(f_), C.byref(nd_), C.byref(pad_))
+    vdb_, vdu_, vdn_ = C.c_int(), C.c_int(), C.c_int32()
+    L.phip_mat_value_dict_info(hA, C.byref(vdb_), C.byref(vdu_), C.byref(vdn_))
+    dmb_, dmu_, dmn_ = C.c_int(), C.c_int(), C.c_int32()
+    L.phip_mat_diag_mask_info(hA, C.byref(dmb_), C.byref(dmu_), C.byref(dmn_))
+    hb_, hu_ = C.c_int(), C.c_int()
+    L.phip_mat_hot_columns_info(hA, C.byref(hb_), C.byref(hu_), None, None)
+    alg = 12 * nz + 20 * m + 4
+    nsl = (m + 511) // 512
+    if f_.value != 2:
+        nb = C.c_int32()
+        L.phip_mat_plan_info(hA, C.byref(nb), None, None, None)
+        real = 12 * nz + 4 * (m + 1) + 8 * n + 8 * m + 5 * nb.value + (20 * n if hu_.value else 0)
+        return "spmv_rowblock_kernel", "CSR row blocks (12 B/nz)" + (", x gathered in hot-column order (+20 B/column)" if hu_.value else ""), real, alg
+    if dmu_.value:
+        return ("spmv_dmask_kernel", "diagonal masks: %d (diagonal, value) pairs, a 32-bit set of them per row (4 B/row)" % dmn_.value,
+                4 * 512 * nsl + 8 * n + 8 * m, alg)
+    if vdu_.value:
+        return ("spmv_pair_kernel", "SELL-dict with a pair dictionary of %d (diagonal, value) pairs (1 B/nz)" % vdn_.value,
+                ((pad_.value + 3) // 4) * 4 + m + 8 * nsl + 8 * n + 8 * m, alg)
+    return "spmv_sell_kernel", "SELL-dict, streamed values (8 B value + 1 B diagonal code per stored entry)", 9 * pad_.value + m + 8 * nsl + 8 * n + 8 * m, alg
+
+
+def traffic_for(workload, kernel):
+    """HBM bytes per launch from a committed rocprofv3 --pmc measurement of THIS workload and kernel (profiles/r02_hbm_traffic.json,
+    written by scripts/collect_profiles.sh on the GPU box), or None.  Offline by nature: a process cannot count its own HBM traffic."""
+    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    try:
+        e = json.load(open(path)).get("%s:%s" % (workload, kernel))
+    except (OSError, ValueError):
+        return None, None
+    if not e:
+        return None, None
+    return e.get("bytes_per_launch"), "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE; %s)" % e.get("source", "")
+
+
+def roofline_obj(workload, kernel, layout, real_bytes, alg_bytes, avg_us, pcts, resident_bytes=None, extra=None):
+    ach = real_bytes / (avg_us * 1e-6) / 1e9
+    traffic, src = traffic_for(workload, kernel)
+    o = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+         "traffic": traffic, "traffic_source": src, "bytes_per_launch": int(real_bytes), "avg_launch_us": round(avg_us, 2), "launch_us_p10_p50_p90": pcts,
+         "launches_timed": REPS, "layout": layout,
+         "algorithmic_bytes_per_launch": int(alg_bytes), "effective_GBps": round(alg_bytes / (avg_us * 1e-6) / 1e9, 1),
+         "effective_pct_of_peak": round(alg_bytes / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBPS * 100, 1),
+         "achieved_is": "bytes the kernel moves in its device layout (x and y once each) / average launch time; effective_GBps prices the same time on the algorithmic CSR bytes 12 nz + 20 m + 4 of SURVEY.md 8d"}
+    if resident_bytes is not None and resident_bytes < (240 << 20):
+        o["cache_note"] = "working set %.0f MB fits the 256 MiB Infinity Cache: back-to-back launches are served on-die, achieved is cache bandwidth, not HBM" % (resident_bytes / 1e6)
+    if extra:
+        o.update(extra)
+    return o
+
+
+def vec_kernels(L, ctx, tm, m):
+    """the two vector launches of a KSPCG iteration (cg.c:222-229 batch with its three fused sums; VecAYPX cg.c:202), back to back"""
+    from petsc_amd.capi import Context, Ticket
+    dev = Context.__new__(Context)
+    dev.lib, dev.h = L, ctx
+    vecs = [dev.to_device(np.linspace(0.1, 1.0, m) * (k + 1)) for k in range(5)]
+    vx, vp, vr, vw, vd = vecs
+    vz = vw  # KSPCG keeps W and Z in one work vector (cg.c:106)
+    tk = Ticket()
+
+    def cg_batch():
+        L.phip_vec_axpy(ctx, m, vx, 1e-3, vp)
+        L.phip_vec_axpy(ctx, m, vr, -1e-3, vw)
+        L.phip_vec_pointwise_mult_reduce(ctx, m, vz, vd, vr, 0, C.byref(tk))
+
+    def aypx():
+        L.phip_vec_aypx(ctx, m, vp, 0.5, vz)
+        L.phip_stream(ctx)  # launches what is pending: one AYPX per launch, as inside the iteration
+
+    out = {}
+    for name, kern, fn, nbytes, what in (("cg_batch", "cg_update_kernel", cg_batch, 64 * m, "VecAXPY(X,a,P) + VecAXPY(R,-a,W) + VecPointwiseMult(Z,D,R) with 3 fused sums, one launch: 5 vectors read, 3 written"),
+                                         ("aypx", "ew_kernel<AYPX>", aypx, 24 * m, "VecAYPX(P,b,Z): 2 vectors read, 1 written")):
+        avg, pcts = tm.kernel(fn, REPS, 10)
+        out[name] = roofline_obj("", kern, "contiguous double[m]", nbytes, nbytes, avg, pcts, resident_bytes=nbytes, extra={"what": what})
+    for v in vecs:
+        dev.free(v)
+    return out
+
+
+def spmv_leg(P, L, comm, tm, name, kind, n, perturb, with_cg, steps, fmt_csr_too=False):
+    """single-GPU leg: SpMV roofline of the layout the library picks (and, fmt_csr_too, of the CSR row-block kernel on the same matrix)"""
+    t0 = time.time()
+    N, m, rs, ai, aj, aa = local_rows(kind, n, 1, 0, "strong", perturb)
+    nz = int(ai[-1])
+    A = P.Mat.seqaij_with_arrays(comm, m, m, ai, aj, aa)
+    setup_s = time.time() - t0
+    hA = A.device_mat(0)
+    x, y = A.create_vecs()
+    x.set_array(np.linspace(-1.0, 1.0, m))
+    dx, dy = x.device_ptr(), y.device_ptr()
+    out = {"matrix": "3-D %s-point %s %d^3%s" % ("7" if kind == "lap7" else "27", "Laplacian" if kind == "lap7" else "box stencil", n,
+                                                  ", every entry perturbed by <= 1e-3 (no two values alike)" if perturb else ""),
+           "rows": m, "nnz": nz, "setup_s": round(setup_s, 2)}
+    kernel, layout, real, alg = layout_of(L, hA, m, m, nz)
+    avg, pcts = tm.kernel(lambda: L.phip_mat_mult(hA, dx, dy))
+    out["roofline"] = roofline_obj(name, kernel, layout, real, alg, avg, pcts, resident_bytes=real)
+    if fmt_csr_too:
+        assert L.phip_mat_set_format(hA, 1) == 0
+        k2, l2, r2, a2 = layout_of(L, hA, m, m, nz)
+        avg2, p2 = tm.kernel(lambda: L.phip_mat_mult(hA, dx, dy))
+        out["roofline_csr"] = roofline_obj(name, k2, l2, r2, a2, avg2, p2, resident_bytes=r2)
+        assert L.phip_mat_set_format(hA, 0) == 0
+    if with_cg:
+        b = y.duplicate()
+        x.set(1.0)
+        A.mult(x, b)
+        ksp = P.KSP(comm, "cg", "jacobi")
+        ksp.set_operators(A)
+        ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=max(steps // 4, 5))
+        ksp.solve(b, x)
+        ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=steps)
+        L.phip_device_sync(comm.ctx)
+        t1 = time.perf_counter()
+        res = ksp.solve(b, x)
+        L.phip_device_sync(comm.ctx)
+        dt = time.perf_counter() - t1
+        assert res["its"] == steps
+        out["cg_iters_per_s"] = round(steps / dt, 1)
+        out["cg_GBps_algorithmic"] = round((alg + 136 * m) * steps / dt / 1e9, 1)
+        ksp.destroy(); b.destroy()
+    for o in (x, y, A):
+        o.destroy()
+    return out
 
 
 def main():
@@ -61,11 +258,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="lap7_128")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--workload", default="box27_256")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
+    ap.add_argument("--legs", default="auto", help="auto (N=1: lap7_128,lap7_256_var) | none | comma-separated names")
     ap.add_argument("--ksp", default="cg", choices=["cg", "pipecg"], help="developer switch; the judged metric is KSPCG")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,7 +283,7 @@ def main():
 
     from petsc_amd import capi, petsc as P
     kind, n = parse_workload(a.workload)
-
+    backend = "self"
     if world > 1:
         # data path: RCCL (one GPU per rank).  PHIP_BENCH_BACKEND=shm stages the ghost exchange through host shared memory instead, so
         # that the ranks may share a GPU: a rehearsal of this script's distributed flow on a one-GPU box, not a measurement.
@@ -97,6 +295,7 @@ def main():
     else:
         comm = P.Comm(device=0, backend="self")
     L = capi.load()
+    tm = Timer(L, comm.ctx)
 
     def dsync():
         rc = L.phip_device_sync(comm.ctx)
@@ -112,15 +311,23 @@ def main():
     t0 = time.time()
     N, m, rs, ai, aj, aa = local_rows(kind, n, world, rank, a.scaling)
     nz_local = int(ai[-1])
+    halo = None
     if world > 1:
         A = P.Mat.mpiaij_with_arrays(comm, m, m, N, N, ai, aj, aa)
         blkA, blkB = A.block(0), A.block(1)
         nzA, nzB, mB = blkA["nz"], blkB["nz"], (len(blkB["cprow_rindex"]) if blkB["cprow_use"] else m)
         del blkA, blkB
+        gh = A.ghosts()
+        halo = {"ghost_entries_received": int(len(gh["garray"])), "entries_sent": int(len(gh["to_indices"])), "neighbours_to": [int(p) for p in gh["to_procs"]],
+                "neighbours_from": [int(p) for p in gh["from_procs"]], "bytes_per_matmult": int(8 * (len(gh["garray"]) + len(gh["to_indices"])))}
+        del gh
     else:
         A = P.Mat.seqaij_with_arrays(comm, m, m, ai, aj, aa)
         nzA, nzB, mB = nz_local, 0, 0
     setup_s = time.time() - t0
+    keep_host_csr = world == 1 and rank == 0 and not a.no_cpu_baseline
+    if not keep_host_csr:
+        del ai, aj, aa
     x, b = A.create_vecs()
     x.set(1.0)
     A.mult(x, b)  # b = A * 1
@@ -131,33 +338,8 @@ def main():
         ksp.set_tolerances(rtol=0.0, abstol=1e-300, dtol=1e300, max_it=its)
         return ksp.solve(b, x)
 
-    # which device layout did the library choose for the (diagonal-block) matrix?  read it through a kernel-level handle of the same CSR
-    fmt_probe = capi.Context.__new__(capi.Context)
-    fmt_probe.lib, fmt_probe.h = L, comm.ctx
-    blk = A.block(0)
-    hA = fmt_probe.mat_create(blk["m"], blk["n"], blk["i"], blk["j"], blk["a"])
-    f_, nd_, pad_ = C.c_int(), C.c_int32(), C.c_int64()
-    L.phip_mat_format_info(hA, C.byref(f_), C.byref(nd_), C.byref(pad_))
-    blk_m, blk_n = blk["m"], blk["n"]
-    del blk
-    # bytes the chosen layout really streams per launch: SELL-dict 9 B per (padded) entry + 1 B row length + x + y (+ slice pointers)
-    # (1 B per entry when the matrix has <= 256 distinct (diagonal, value) pairs: the pair dictionary)
-    vdb_, vdu_, vdn_ = C.c_int(), C.c_int(), C.c_int32()
-    L.phip_mat_value_dict_info(hA, C.byref(vdb_), C.byref(vdu_), C.byref(vdn_))
-    # (a 32-bit set of pairs per ROW when there are <= 32 of them: the diagonal-mask layout)
-    dmb_, dmu_, dmn_ = C.c_int(), C.c_int(), C.c_int32()
-    L.phip_mat_diag_mask_info(hA, C.byref(dmb_), C.byref(dmu_), C.byref(dmn_))
-    entry_bytes = 1 if vdu_.value else 9
-    if f_.value != 2:
-        layout_bytes, kernel_name, layout_name = 12 * nzA + 20 * m + 4, "spmv_rowblock_kernel", "CSR row blocks (12 B/nz)"
-    elif dmu_.value:
-        layout_bytes, kernel_name = 20 * m, "spmv_dmask_kernel"
-        layout_name = "diagonal masks: %d (diagonal, value) pairs, a 32-bit set of them per row (4 B/row)" % dmn_.value
-    else:
-        layout_bytes = entry_bytes * pad_.value + 17 * m + 8 * ((m + 511) // 512)
-        kernel_name = "spmv_pair_kernel" if vdu_.value else "spmv_sell_kernel"
-        layout_name = "SELL-dict, pair dictionary of %d (diagonal, value) pairs (1 B/nz)" % vdn_.value if vdu_.value else "SELL-dict (9 B/nz)"
-    spmv_bytes = 12 * nzA + 20 * m + 4
+    hA = A.device_mat(0)
+    kernel_name, layout_name, real_bytes, spmv_bytes = layout_of(L, hA, m, m, nzA)
     spmv_add_bytes = (12 * nzB + 28 * mB) if nzB else 0
     iter_bytes = spmv_bytes + spmv_add_bytes + 136 * m
 
@@ -168,115 +350,117 @@ def main():
     res = run(a.steps)
     barrier()
     dt = time.perf_counter() - t1
-    cnt, sm, mn, mx = C.c_int32(), C.c_double(), C.c_double(), C.c_double()
-    L.phip_profile_read(comm.ctx, 0, C.byref(cnt), C.byref(sm), C.byref(mn), C.byref(mx))
+    cap = a.steps + 8
+    dur = (C.c_float * cap)()
+    cnt = C.c_int32()
+    L.phip_profile_durations(comm.ctx, 0, cap, dur, C.byref(cnt))
     L.phip_profile_enable(comm.ctx, 0)
     assert res["its"] == a.steps, "CG stopped after %d of %d iterations (reason %d)" % (res["its"], a.steps, res["reason"])
-    spmv_ms = sm.value / max(cnt.value, 1)
+    incg = [dur[i] for i in range(min(cnt.value, cap))]
+    spmv_ms = float(np.mean(incg)) if incg else 0.0
 
-    # SpMV alone, back to back (hipEvents around the whole loop): the figure BASELINE.json's 70 % target is quoted on.  The roofline
-    # kernel is timed on the kernel-level handle of the (diagonal-block) matrix: the same kernel, without the ghost exchange that a
-    # MatMult on several ranks waits for; the whole MatMult is timed beside it.
-    reps = 200
-    dxr = fmt_probe.to_device(np.linspace(-1.0, 1.0, max(blk_n, 1)))
-    dyr = fmt_probe.to_device(np.zeros(max(blk_m, 1)))
-    for _ in range(20):
-        L.phip_mat_mult(hA, dxr, dyr)
-    dsync()
-    b2b_ms = min(fmt_probe.time_region(lambda: L.phip_mat_mult(hA, dxr, dyr), reps) for _ in range(3))
-    fmt_probe.free(dxr); fmt_probe.free(dyr)
-    L.phip_mat_destroy(hA)
-    for _ in range(20):
-        A.mult(x, b)
-    dsync()
-    matmult_ms = min(fmt_probe.time_region(lambda: A.mult(x, b), reps) for _ in range(3))
+    # the diagonal-block SpMV kernel alone (kernel-level handle of the matrix the solve used), then the whole MatMult (ghost exchange
+    # + diagonal block + off-diagonal block on N > 1)
+    dxr, dyr = x.device_ptr(), b.device_ptr()
+    xsave = x.array()
+    b2b_us, b2b_pcts = tm.kernel(lambda: L.phip_mat_mult(hA, dxr, dyr))
+    if dist is not None:
+        dist.barrier()
+    y2 = b.duplicate()
+    mm_us, mm_pcts = tm.kernel(lambda: A.mult(x, y2))
+    offd_us = None
+    if world > 1:
+        hB = A.device_mat(1)
+        lv = capi.Context.__new__(capi.Context)
+        lv.lib, lv.h = L, comm.ctx
+        dl = lv.to_device(np.zeros(max(halo["ghost_entries_received"], 1)))
+        dy2 = y2.device_ptr()
+        offd_us, _ = tm.kernel(lambda: L.phip_mat_multadd(hB, dl, dy2, dy2))
+        lv.free(dl)
+    y2.destroy()
+    x.set_array(xsave)
+    vk = vec_kernels(L, comm.ctx, tm, m)
 
-    # the two vector launches of a KSPCG iteration, back to back like the SpMV above (rank 0's figures are reported): the batch
-    # VecAXPY(X,a,P) + VecAXPY(R,-a,W) + PCApply_Jacobi(R,Z) with its three fused sums (cg.c:222-229: 5 vectors read, 3 written), and
-    # VecAYPX(P,b,Z) (cg.c:252: 2 read, 1 written)
-    from petsc_amd.capi import Ticket
-    vecs = [fmt_probe.to_device(np.linspace(0.1, 1.0, m) * (k + 1)) for k in range(7)]
-    vx, vp, vr, vw, vd, _, _ = vecs
-    vz = vw   # KSPCG keeps W and Z in one work vector (cg.c:106)
-    tk = Ticket()
-
-    def cg_batch():
-        L.phip_vec_axpy(comm.ctx, m, vx, 1e-3, vp)
-        L.phip_vec_axpy(comm.ctx, m, vr, -1e-3, vw)
-        L.phip_vec_pointwise_mult_reduce(comm.ctx, m, vz, vd, vr, 0, C.byref(tk))
-
-    def aypx():
-        L.phip_vec_aypx(comm.ctx, m, vp, 0.5, vz)
-        L.phip_stream(comm.ctx)   # launches what is pending: one AYPX per launch, as inside the iteration
-
-    vec_ms = {}
-    for name, fn in (("cg_batch", cg_batch), ("aypx", aypx)):
-        for _ in range(10):
-            fn()
-        dsync()
-        vec_ms[name] = min(fmt_probe.time_region(fn, reps) for _ in range(3))
-    for v in vecs:
-        fmt_probe.free(v)
-
-    tot_bytes = np.array([float(iter_bytes), float(dt), float(spmv_ms), float(spmv_bytes + spmv_add_bytes), float(b2b_ms)])
+    tot = np.array([float(iter_bytes), float(spmv_bytes + spmv_add_bytes), float(dt), float(spmv_ms), float(b2b_us), float(mm_us), float(m), float(nz_local)])
     if dist is not None:
         import torch
-        tb = torch.tensor([tot_bytes[0], tot_bytes[3]], dtype=torch.float64)
+        tb = torch.tensor([tot[0], tot[1]], dtype=torch.float64)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
-        tm = torch.tensor([tot_bytes[1], tot_bytes[2], tot_bytes[4]], dtype=torch.float64)
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        tmx = torch.tensor([tot[2], tot[3], tot[4], tot[5], tot[6], tot[7]], dtype=torch.float64)
+        dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+        tmn = torch.tensor([tot[6], tot[7]], dtype=torch.float64)
+        dist.all_reduce(tmn, op=dist.ReduceOp.MIN)
         job_iter_bytes, job_spmv_bytes = float(tb[0]), float(tb[1])
-        dt, spmv_ms_max, b2b_ms = float(tm[0]), float(tm[1]), float(tm[2])
+        dt, spmv_ms_max, b2b_us_max, mm_us_max = float(tmx[0]), float(tmx[1]), float(tmx[2]), float(tmx[3])
+        rows_minmax, nnz_minmax = [int(tmn[0]), int(tmx[4])], [int(tmn[1]), int(tmx[5])]
     else:
-        job_iter_bytes, job_spmv_bytes, spmv_ms_max = float(iter_bytes), float(spmv_bytes), spmv_ms
+        job_iter_bytes, job_spmv_bytes, spmv_ms_max, b2b_us_max, mm_us_max = float(iter_bytes), float(spmv_bytes), spmv_ms, b2b_us, mm_us
+        rows_minmax, nnz_minmax = [m, m], [nz_local, nz_local]
 
     out = None
     if rank == 0:
         ms_per_step = dt * 1e3 / a.steps
         value = job_iter_bytes * a.steps / dt / 1e9
-        achieved = spmv_bytes / (b2b_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(a.workload)
+        resident = real_bytes + 8 * m * 6
+        spmv_roof = roofline_obj(a.workload if world == 1 else "%s/%d" % (a.workload, world), kernel_name, layout_name, real_bytes, spmv_bytes, b2b_us, b2b_pcts,
+                                 resident_bytes=resident)
+        spmv_roof["avg_launch_us_inside_cg"] = round(spmv_ms * 1e3, 2)
+        spmv_roof["launch_us_inside_cg_p10_p50_p90"] = [round(pct(incg, q) * 1e3, 2) for q in (10, 50, 90)] if incg else None
+        spmv_roof["inside_cg_note"] = "inside KSPCG the product also leaves sum_i x_i y_i (the VecTDot(P,W) of cg.c:207) and is bracketed by an event pair per launch"
+        # which kernel owns the largest share of the timed iteration?
+        shares = {"spmv": spmv_ms * 1e3 if incg else b2b_us, "cg_batch": vk["cg_batch"]["avg_launch_us"], "aypx": vk["aypx"]["avg_launch_us"]}
+        dom = max(shares, key=shares.get)
+        roof = dict(spmv_roof if dom == "spmv" else vk[dom])
+        roof["share_of_iteration_us"] = {k: round(v, 2) for k, v in shares.items()}
+        roof["why_this_kernel"] = "largest share of the timed KSPCG iteration (kernel times above; the rest of %.1f us per step is two host round trips for the reductions)" % (ms_per_step * 1e3)
         out = {
-            "metric": "SpMV effective HBM GB/s (% of peak) + KSPCG iters/sec",
+            "metric": "SpMV effective HBM GB/s (% of peak) + KSPCG iters/sec at 1/2/4/8 GPUs",
             "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "KSPCG+PCJACOBI step (MatMult + Krylov vector kernels) on the 3-D %s-point %s, %d^3 rows per GPU, MAT%sAIJHIP/VEC%sHIP, int32/f64"
-                       % ("7" if kind == "lap7" else "27", "Laplacian" if kind == "lap7" else "box stencil", n,
-                          "SEQ" if world == 1 else "MPI", "SEQ" if world == 1 else "MPI"),
-                       "name": a.workload, "global_rows": N, "rows_per_gpu": m, "nnz_per_gpu": nz_local,
-                       "partition": "MPIAIJ row blocks (z-slabs)", "value_is": "algorithmic bytes of one CG iteration x K / wall time, all ranks"},
+            "config": {"workload": "KSPCG+PCJACOBI step (MatMult + Krylov vector kernels) on the 3-D %s-point %s %d^3%s, MAT%sAIJHIP/VEC%sHIP, int32/f64, %s scaling over MPIAIJ row blocks"
+                       % ("7" if kind == "lap7" else "27", "Laplacian" if kind == "lap7" else "box stencil", n, " per GPU" if a.scaling == "weak" else " (global)",
+                          "SEQ" if world == 1 else "MPI", "SEQ" if world == 1 else "MPI", a.scaling),
+                       "name": a.workload, "global_rows": N, "rows_per_gpu_min_max": rows_minmax, "nnz_per_gpu_min_max": nnz_minmax,
+                       "partition": "MPIAIJ row blocks (z-slabs)", "value_is": "algorithmic bytes of one CG iteration x K / wall time, all ranks (max over ranks)"},
             "cg_iters_per_s": round(a.steps / dt, 1),
-            "spmv": {"GBps_in_cg": round(job_spmv_bytes / (spmv_ms_max * 1e-3) / 1e9, 1),
-                     "GBps_back_to_back": round(spmv_bytes * world / (b2b_ms * 1e-3) / 1e9, 1),
-                     "pct_of_8TBps_back_to_back": round(spmv_bytes / (b2b_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS * 100, 1),
-                     "us_in_cg": round(spmv_ms_max * 1e3, 2), "us_back_to_back": round(b2b_ms * 1e3, 2),
-                     "matmult_us_back_to_back_rank0": round(matmult_ms * 1e3, 2),
-                     "bytes": spmv_bytes, "launches_timed": cnt.value},
-            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "bytes_per_launch": spmv_bytes, "avg_launch_us": round(b2b_ms * 1e3, 2),
-                         "layout": layout_name, "layout_bytes_per_launch": layout_bytes,
-                         "layout_GBps": round(layout_bytes / (b2b_ms * 1e-3) / 1e9, 1), "layout_frac": round(layout_bytes / (b2b_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "note": "achieved = ALGORITHMIC CSR bytes (12 nz + 20 m + 4, SURVEY.md 8d) / launch time; the stencil layouts stream fewer bytes (layout_*: SELL-dict 9 B/nz; 1 B/nz when the matrix has <= 256 distinct (diagonal, value) pairs; 4 B/row when <= 32; all lossless, same bits; PHIP_VALUE_DICT=0 streams the values), and the 128^3 working set fits the 256 MiB Infinity Cache, so achieved can exceed the HBM peak",
-                         "how": "%d launches back to back between two hipEvents on the library's compute stream, best of 3 (rocprofv3 average of the same kernel: profiles/)" % reps,
-                         "avg_launch_us_inside_cg_event_pairs": round(spmv_ms * 1e3, 2), "achievable_peak_note": "6.29 TB/s measured float4 copy (MI355X_MICROARCH.md)"},
-            "vector_kernels": {
-                "bound": "hbm (here: Infinity Cache, the iteration's working set fits it)" if 8 * m * 7 + layout_bytes < (200 << 20) else "hbm",
-                "cg_batch": {"kernel": "cg_update_kernel", "what": "VecAXPY(X,a,P) + VecAXPY(R,-a,W) + VecPointwiseMult(Z,D,R) with 3 fused sums, one launch",
-                             "bytes_per_launch": 64 * m, "avg_launch_us": round(vec_ms["cg_batch"] * 1e3, 2),
-                             "GBps": round(64 * m / (vec_ms["cg_batch"] * 1e-3) / 1e9, 1), "frac": round(64 * m / (vec_ms["cg_batch"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
-                "aypx": {"kernel": "ew_kernel<AYPX>", "bytes_per_launch": 24 * m, "avg_launch_us": round(vec_ms["aypx"] * 1e3, 2),
-                         "GBps": round(24 * m / (vec_ms["aypx"] * 1e-3) / 1e9, 1), "frac": round(24 * m / (vec_ms["aypx"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}},
+            "spmv": {"effective_GBps_back_to_back": round(job_spmv_bytes / (mm_us_max * 1e-6) / 1e9, 1),
+                     "effective_pct_of_8TBps_per_gpu": round(job_spmv_bytes / world / (mm_us_max * 1e-6) / 1e9 / HBM_PEAK_GBPS * 100, 1),
+                     "effective_GBps_in_cg": round(job_spmv_bytes / (spmv_ms_max * 1e-3) / 1e9, 1) if spmv_ms_max else None,
+                     "matmult_us_back_to_back": round(mm_us_max, 2), "matmult_us_p10_p50_p90_rank0": mm_pcts,
+                     "diag_block_kernel_us": round(b2b_us_max, 2), "offdiag_block_kernel_us_rank0": round(offd_us, 2) if offd_us is not None else None,
+                     "algorithmic_bytes_all_ranks": int(job_spmv_bytes), "launches_timed": REPS,
+                     "note": "matmult = the whole MatMult (N > 1: pack + ghost exchange overlapped with the diagonal block, then the off-diagonal block); exchange cost not hidden = matmult - diag - offdiag"},
+            "roofline": roof,
+            "kernels": {"spmv": spmv_roof, "cg_batch": vk["cg_batch"], "aypx": vk["aypx"]},
             "final_rnorm": res["rnorm"], "setup_s": round(setup_s, 2),
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ai, aj, aa, m, iter_bytes, spmv_bytes, a.cpu_seconds)
+        if world > 1:
+            hc = comm.hip_comm()
+            rr, ss = C.c_int(), C.c_int()
+            L.phip_comm_rank_size(hc, C.byref(rr), C.byref(ss))
+            out["multi_gpu"] = {"backend": backend, "rccl_ranks": ss.value if backend == "rccl" else 0, "comm_ranks": ss.value, "halo_rank0": halo,
+                                "reductions": "host shared-memory ring" if not os.environ.get("PETSCHIP_DEVICE_ALLREDUCE") else "ncclAllReduce"}
     for o in (ksp, x, b, A):
         o.destroy()
+
+    if rank == 0 and world == 1:
+        legs = a.legs
+        if legs == "auto":
+            legs = "lap7_128,lap7_256_var"
+        out["legs"] = {}
+        for leg in [s for s in legs.split(",") if s and s != "none"]:
+            if leg == "lap7_128":
+                out["legs"][leg] = spmv_leg(P, L, comm, tm, leg, "lap7", 128, False, True, max(a.steps, 20))
+                out["legs"][leg]["is"] = "BASELINE configs[1]: SeqAIJ SpMV + CG on the 3-D 7-point Laplacian 128^3 (target: SpMV >= 70 % of HBM peak on the algorithmic bytes)"
+            elif leg == "lap7_256_var":
+                out["legs"][leg] = spmv_leg(P, L, comm, tm, leg, "lap7", 256, True, False, a.steps, fmt_csr_too=True)
+                out["legs"][leg]["is"] = "out-of-cache, non-dictionary SpMV: the general stencil path (SELL-dict streamed values) and the general CSR row-block kernel on the same matrix"
+            else:
+                k2, n2 = parse_workload(leg)
+                out["legs"][leg] = spmv_leg(P, L, comm, tm, leg, k2, n2, False, True, max(a.steps, 20))
+        if keep_host_csr:
+            out["cpu_baseline"] = cpu_baseline(ai, aj, aa, m, iter_bytes, spmv_bytes, a.cpu_seconds)
     comm.finalize()
     if dist is not None:
         dist.barrier()
@@ -285,46 +469,61 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(ai, aj, aa, m, iter_bytes, spmv_bytes, seconds):
-    """The oracle (oracle/petsc_oracle.c, gcc -O3 -march=native -fopenmp) on the host: KSPCG+PCJACOBI iterations of the same system,
-    (i) as MATMPIAIJ would run it on P cores -- P row blocks, one thread each (P = this job's CPU share) -- and (ii) on one core
-    (MATSEQAIJ).  SURVEY.md 8d."""
-    from oracle.oracle import Oracle
-    orc = Oracle(fast=True)
+def host_cores():
+    """(cpus this job may use, physical cores of the machine, logical cpus of the machine)"""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    P = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), avail, 16))
+    phys = None
+    try:
+        txt = subprocess.run(["lscpu", "-p=core,socket"], capture_output=True, text=True, timeout=10).stdout
+        phys = len({l for l in txt.splitlines() if l and not l.startswith("#")})
+    except Exception:
+        pass
+    return avail, phys, os.cpu_count()
+
+
+def cpu_baseline(ai, aj, aa, m, iter_bytes, spmv_bytes, seconds):
+    """The oracle (oracle/petsc_oracle.c, gcc -O3 -march=native -fopenmp) on the host: KSPCG+PCJACOBI iterations of the same system,
+    (i) as MATMPIAIJ would run it on P cores -- P row blocks, one thread each (P = this job's CPU share, at most 16), (ii) on 8 row
+    blocks (the 8-rank partition of the GPU runs), (iii) on one core (MATSEQAIJ).  SURVEY.md 8d."""
+    from oracle.oracle import Oracle
+    orc = Oracle(fast=True)
+    avail, phys, logical = host_cores()
+    Pn = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), avail, 16))
 
     def leg(size, threads, budget):
         op = orc.operator(ai, aj, aa, size, threads)
         bvec = op.mult(np.ones(m))
-        cal = 3 if threads == 1 else 40   # the threaded leg needs a longer run-in (first touch, thread start) for a fair estimate
-        op.solve(bvec, "cg", "jacobi", rtol=1e-300, abstol=1e-300, divtol=1e300, max_it=3)
+        cal = 2 if threads == 1 else 10   # the threaded legs need a run-in (first touch, thread start) for a fair estimate
+        op.solve(bvec, "cg", "jacobi", rtol=1e-300, abstol=1e-300, divtol=1e300, max_it=2)
         t = time.perf_counter()
         op.solve(bvec, "cg", "jacobi", rtol=1e-300, abstol=1e-300, divtol=1e300, max_it=cal)
         per = (time.perf_counter() - t) / (cal + 1.0)
-        its = int(max(5, min(5000, budget / max(per, 1e-6))))
+        its = int(max(3, min(5000, budget / max(per, 1e-6))))
         t = time.perf_counter()
         r = op.solve(bvec, "cg", "jacobi", rtol=1e-300, abstol=1e-300, divtol=1e300, max_it=its)
         dt = time.perf_counter() - t
         t = time.perf_counter()
-        nmult = 5
+        nmult = 3
         for _ in range(nmult):
             op.mult(bvec)
         dts = (time.perf_counter() - t) / nmult
-        return r["its"], dt, dts
+        return {"value": round(iter_bytes * r["its"] / dt / 1e9, 2), "unit": "GB/s", "cores": threads, "kind": "port",
+                "cg_iters_per_s": round(r["its"] / dt, 2), "spmv_GBps": round(spmv_bytes / dts / 1e9, 2), "iterations": r["its"], "seconds": round(dt, 1)}
 
-    its1, dt1, dts1 = leg(1, 1, seconds / 2)
-    out = {"value": round(iter_bytes * its1 / dt1 / 1e9, 2), "unit": "GB/s", "cores": 1, "kind": "port",
-           "sample": "%d KSPCG+PCJACOBI iterations of the same matrix and right-hand side by the oracle's C restatement of MatMult_SeqAIJ/Vec*_Seq (one thread, gcc -O3 -march=native), %.1f s" % (its1, dt1),
-           "cg_iters_per_s": round(its1 / dt1, 2), "spmv_GBps": round(spmv_bytes / dts1 / 1e9, 2)}
-    if P > 1:
-        itsP, dtP, dtsP = leg(P, P, seconds / 2)
-        out = {"value": round(iter_bytes * itsP / dtP / 1e9, 2), "unit": "GB/s", "cores": P, "kind": "port",
-               "sample": "%d KSPCG+PCJACOBI iterations of the same system by the oracle's C restatement of MatMult_MPIAIJ/Vec*_MPI: %d row blocks (MPIAIJ's partition), one OpenMP thread each (gcc -O3 -march=native -fopenmp), %.1f s; one_core = the same on a single thread" % (itsP, P, dtP),
-               "cg_iters_per_s": round(itsP / dtP, 2), "spmv_GBps": round(spmv_bytes / dtsP / 1e9, 2), "one_core": out}
+    one = leg(1, 1, seconds / 4)
+    out = one
+    if Pn > 1:
+        out = leg(Pn, Pn, seconds / 2)
+        out["one_core"] = one
+        if Pn >= 8:
+            out["eight_row_blocks"] = leg(8, 8, seconds / 4)
+    out["sample"] = ("%d KSPCG+PCJACOBI iterations (%.1f s) of the same system by the oracle's C restatement of MatMult_MPIAIJ / Vec*_MPI on %d row blocks (MPIAIJ's partition), "
+                     "one OpenMP thread each (gcc -O3 -march=native -fopenmp); one_core = MatMult_SeqAIJ / Vec*_Seq on a single thread; eight_row_blocks = 8 threads, the partition of the 8-GPU run"
+                     % (out["iterations"], out["seconds"], out["cores"]))
+    out["host"] = {"cpus_available_to_this_job": avail, "physical_cores_of_the_machine": phys, "logical_cpus_of_the_machine": logical}
     return out
 
 

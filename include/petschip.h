@@ -83,6 +83,8 @@ int         phip_event_destroy(phip_ctx ctx, void *event);
  * durations in ms.  Enabling (or re-enabling) clears the records. */
 int         phip_profile_enable(phip_ctx ctx, int on);
 int         phip_profile_read(phip_ctx ctx, int kind, int32_t *count, double *sum_ms, double *min_ms, double *max_ms);
+/* the individual durations (ms, launch order) behind phip_profile_read: at most cap are written to h_ms, *count = launches recorded */
+int         phip_profile_durations(phip_ctx ctx, int kind, int32_t cap, float *h_ms, int32_t *count);
 
 /* ---- device CSR matrix (Mat_SeqAIJ on the GPU) --------------------------------------------------
  * phip_mat_create uploads a host CSR exactly as MatAssemblyEnd_SeqAIJ leaves it (src/mat/impls/aij/seq/aij.c:
@@ -114,6 +116,9 @@ int phip_mat_getdiagonal(phip_mat A, double *d_v);
 /* Row-block plan introspection (tests): number of blocks, nnz capacity per block, threads per row used. */
 int phip_mat_plan_info(phip_mat A, int32_t *nblocks, int32_t *block_nnz_cap, int32_t *threads_per_row, int64_t *nnz);
 int phip_mat_plan_get(phip_mat A, int32_t *h_block_row /* nblocks+1 */);
+/* the row binning of the plan (BASELINE config 5 "load-imbalance / row binning"): h_hist[l], l = 0..6, = number of row blocks whose rows
+ * are summed by 2^l lanes each; h_hist[7] = number of rows longer than a block's capacity (a whole workgroup strides over such a row) */
+int phip_mat_plan_lanes(phip_mat A, int64_t *h_hist /* [8] */);
 /* Device layout.  1 = CSR row blocks (any matrix).  2 = "SELL-dict": 512-row slices stored slot-major with a one-byte index into the
  * table of distinct diagonals (col - row) in place of the 4-byte column: 9 instead of 12 bytes per nonzero; built at upload when the
  * matrix has <= 256 distinct diagonals, rows of <= 255 entries and < 15 % slice padding (the stencil matrices of DMDA; the
@@ -144,6 +149,9 @@ int phip_mat_diag_mask_info(phip_mat A, int *built, int *in_use, int32_t *npairs
 /* tuning: SELL-dict kernel gathers x from LDS-staged contiguous segments (one per cluster of nearby diagonals) instead of through
  * L1/L2; same bits; measured slower on MI355X for 7- and 27-point stencils, hence off by default */
 int phip_mat_set_x_staging(phip_mat A, int on);
+/* tuning: loads of the matrix stream: -1 (default) non-temporal when the stream exceeds 192 MB (it would only displace x from the caches),
+ * 0 always cached, 1 always non-temporal.  Same bits either way. */
+int phip_mat_set_nontemporal(phip_mat A, int mode);
 /* tuning: threads_per_row (0 = auto), 1,2,4,...,64 */
 int phip_mat_set_threads_per_row(phip_mat A, int32_t tpr);
 /* Hot-column order of the CSR row-block layout, for irregular matrices whose x is far larger than L2 and whose columns are used very
@@ -166,6 +174,9 @@ int phip_mat_hot_columns_info(phip_mat A, int *built, int *in_use, double *share
  * entry -- same bits as one launch per operation, fewer launches, operands re-read from cache (PHIP_EW_BATCH=0 in the environment
  * switches the deferral off).  A caller that touches the vectors outside this library asks for phip_stream() or phip_sync() first, as it
  * must for any asynchronous launch. */
+/* tuning, process-wide: non-temporal loads (and stores of X and R in the KSPCG batch) in the elementwise kernels: -1 (default) for vectors
+ * of 48 MiB and more, 0 never, 1 always.  Same bits either way.  PHIP_EW_NT in the environment sets the initial value. */
+int phip_set_ew_nontemporal(int mode);
 int phip_vec_dot(phip_ctx ctx, int32_t n, const double *d_x, const double *d_y, double *h_z);        /* VecDot_Seq/VecTDot_Seq bvec1.c:12-51 */
 int phip_vec_norm(phip_ctx ctx, int32_t n, const double *d_x, int type, double *h_z);                /* VecNorm_Seq bvec2.c:233-271 (h_z[2] for 1_AND_2) */
 int phip_vec_mdot(phip_ctx ctx, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *h_z); /* VecMDot_Seq dvec2.c:98-294 */

@@ -79,6 +79,7 @@ PetscErrorCode PetscHipSetHostReductions(PetscComm comm, PetscBool flg);
 PetscErrorCode PetscCommGetSelf(PetscComm world, PetscComm *self);     /* PETSC_COMM_SELF */
 PetscErrorCode PetscCommRankSize(PetscComm comm, int *rank, int *size); /* MPI_Comm_rank / MPI_Comm_size */
 PetscErrorCode PetscCommGetContext(PetscComm comm, phip_ctx *ctx);
+PetscErrorCode PetscCommGetHipComm(PetscComm comm, phip_comm *hipcomm); /* the libpetschip communicator behind it (phip_comm_rank_size, ...) */
 const char    *PetscHipLastError(void);
 /* PetscSplitOwnership, src/sys/utils/psplit.c:75-97 */
 PetscErrorCode PetscSplitOwnership(PetscComm comm, PetscInt *n, PetscInt *N);
@@ -104,7 +105,8 @@ PetscErrorCode VecRestoreArray(Vec v, PetscScalar **a);
 PetscErrorCode VecGetArrayRead(Vec v, const PetscScalar **a);
 PetscErrorCode VecRestoreArrayRead(Vec v, const PetscScalar **a);
 PetscErrorCode VecHipGetArrayRead(Vec v, const PetscScalar **d_a);  /* device pointer; cf. VecCUSPGetArrayRead veccusp.cu:1993 */
-PetscErrorCode VecHipGetArrayWrite(Vec v, PetscScalar **d_a);       /* device pointer, marks the vector changed */
+PetscErrorCode VecHipGetArrayWrite(Vec v, PetscScalar **d_a);       /* device pointer, marks the vector changed; pending operations are launched first */
+PetscErrorCode VecHipRestoreArrayWrite(Vec v, PetscScalar **d_a);   /* the caller's writes are queued on phip_stream(): bumps the state again (rvector.c:1865) */
 PetscErrorCode VecSet(Vec x, PetscScalar alpha);
 PetscErrorCode VecCopy(Vec x, Vec y);
 PetscErrorCode VecSwap(Vec x, Vec y);
@@ -182,6 +184,8 @@ PetscErrorCode MatDestroy(Mat *A);
  * Any output pointer may be NULL.  cprow_i / cprow_rindex are filled only when *cprow_use != 0. */
 PetscErrorCode MatHipGetBlockInfo(Mat A, int which, PetscInt *m, PetscInt *n, PetscInt *nz, PetscInt *nonzerorowcnt, PetscInt *rmax, PetscBool *cprow_use, PetscInt *cprow_nrows);
 PetscErrorCode MatHipGetBlockArrays(Mat A, int which, PetscInt *i, PetscInt *j, PetscScalar *a, PetscInt *diag, PetscInt *cprow_i, PetscInt *cprow_rindex);
+/* the device matrix (include/petschip.h) behind block `which`: what MatMult launches on; for measurements and plan introspection */
+PetscErrorCode MatHipGetDeviceMat(Mat A, int which, phip_mat *dev);
 /* MPIAIJ multiply set-up products: garray (mmaij.c:69-101) and the VecScatter PtoS plan (vpscat.c:2297-2495) */
 PetscErrorCode MatHipGetGhostInfo(Mat A, PetscInt *ec, PetscInt *to_n, PetscInt *to_len, PetscInt *from_n);
 PetscErrorCode MatHipGetGhostArrays(Mat A, PetscInt *garray, PetscInt *to_procs, PetscInt *to_starts, PetscInt *to_indices, PetscInt *from_procs, PetscInt *from_starts);
@@ -192,6 +196,13 @@ PetscErrorCode MatLoad(Mat A, const char *filename, int64_t *offset);
 PetscErrorCode VecLoad(Vec v, const char *filename, int64_t *offset);
 PetscErrorCode MatView(Mat A, const char *filename, int append);
 PetscErrorCode VecView(Vec v, const char *filename, int append);
+
+/* Harness, not PETSc API: the rows [rstart, rend) of the synthetic stencil matrices of the BASELINE configs (natural ordering, x fastest;
+ * the pattern DMCreateMatrix_DA_3d_MPIAIJ preallocates, src/dm/impls/da/fdda.c:1024: full stencil truncated at the domain boundary), as CSR
+ * with global sorted columns.  kind 7: 7-point, diag 6, off -1;  27: 27-point box, diag 26, off -1;  5: 2-D 5-point (nz must be 1), diag 4,
+ * off -1 (ex2.c:88-95).  Two calls: aj == NULL fills ai[rend - rstart + 1] only (ai[last] = entries to allocate), then with aj / aa.
+ * Same arrays as petsc_amd/generators.py builds with numpy (tests/test_host_cpu.py), 10-20 times faster at 256^3. */
+PetscErrorCode PetscHipStencilRows(int kind, PetscInt nx, PetscInt ny, PetscInt nz, int64_t rstart, int64_t rend, PetscInt *ai, PetscInt *aj, PetscScalar *aa);
 
 /* ---- PC (include/petscpc.h) ---- */
 PetscErrorCode PCCreate(PetscComm comm, PC *pc);

@@ -31,6 +31,7 @@ SIGNATURES = [
     ("phip_event_destroy", C.c_int, [_vp, _vp]),
     ("phip_profile_enable", C.c_int, [_vp, C.c_int]),
     ("phip_profile_read", C.c_int, [_vp, C.c_int, _pI, _pD, _pD, _pD]),
+    ("phip_profile_durations", C.c_int, [_vp, C.c_int, C.c_int32, C.POINTER(C.c_float), _pI]),
     ("phip_mat_create", C.c_int, [_vp, C.c_int32, C.c_int32, _pI, _pI, _pD, C.c_int, C.c_int32, _pI, _pI, C.POINTER(_vp)]),
     ("phip_mat_update_values", C.c_int, [_vp, _pD]),
     ("phip_mat_destroy", C.c_int, [_vp]),
@@ -42,6 +43,9 @@ SIGNATURES = [
     ("phip_mat_getdiagonal", C.c_int, [_vp, _vp]),
     ("phip_mat_plan_info", C.c_int, [_vp, _pI, _pI, _pI, C.POINTER(C.c_int64)]),
     ("phip_mat_plan_get", C.c_int, [_vp, _pI]),
+    ("phip_mat_plan_lanes", C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    ("phip_mat_set_nontemporal", C.c_int, [_vp, C.c_int]),
+    ("phip_set_ew_nontemporal", C.c_int, [C.c_int]),
     ("phip_mat_set_threads_per_row", C.c_int, [_vp, C.c_int32]),
     ("phip_set_default_mat_format", C.c_int, [C.c_int]),
     ("phip_mat_set_format", C.c_int, [_vp, C.c_int]),

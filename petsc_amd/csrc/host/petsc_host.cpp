@@ -173,6 +173,45 @@ extern "C" PetscErrorCode PetscCommGetContext(PetscComm c, phip_ctx *ctx)
   return 0;
 }
 
+extern "C" PetscErrorCode PetscCommGetHipComm(PetscComm c, phip_comm *hipcomm)
+{
+  if (!c || !hipcomm) SETERRQ(PETSC_ERR_ARG_NULL, "PetscCommGetHipComm: null argument");
+  *hipcomm = c->comm;
+  return 0;
+}
+
+/* harness: rows of the synthetic stencil matrices (include/petschip_host.h) */
+extern "C" PetscErrorCode PetscHipStencilRows(int kind, PetscInt nx, PetscInt ny, PetscInt nz, int64_t rstart, int64_t rend, PetscInt *ai, PetscInt *aj, PetscScalar *aa)
+{
+  if (!ai) SETERRQ(PETSC_ERR_ARG_NULL, "PetscHipStencilRows: null row pointer");
+  if (kind != 5 && kind != 7 && kind != 27) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "PetscHipStencilRows: kind %d", kind);
+  if (nx < 1 || ny < 1 || nz < 1 || (kind == 5 && nz != 1)) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "PetscHipStencilRows: grid %d x %d x %d", nx, ny, nz);
+  const int64_t N = (int64_t)nx * ny * nz;
+  if (rstart < 0 || rend < rstart || rend > N || N > 2147483647ll) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "PetscHipStencilRows: rows [%lld, %lld) of %lld", (long long)rstart, (long long)rend, (long long)N);
+  const bool   box = kind == 27;
+  const double dg = kind == 27 ? 26.0 : (kind == 7 ? 6.0 : 4.0);
+  int64_t      w = 0;
+  ai[0] = 0;
+  for (int64_t r = rstart; r < rend; r++) {
+    const int i = (int)(r % nx), j = (int)((r / nx) % ny), k = (int)(r / ((int64_t)nx * ny));
+    for (int dz = -1; dz <= 1; dz++) {
+      if (k + dz < 0 || k + dz >= nz) continue;
+      for (int dy = -1; dy <= 1; dy++) {
+        if (j + dy < 0 || j + dy >= ny) continue;
+        for (int dx = -1; dx <= 1; dx++) {
+          if (i + dx < 0 || i + dx >= nx) continue;
+          if (!box && (dx != 0) + (dy != 0) + (dz != 0) > 1) continue;
+          if (aj) { aj[w] = (PetscInt)(r + dx + (int64_t)nx * (dy + (int64_t)ny * dz)); aa[w] = (dx || dy || dz) ? -1.0 : dg; }
+          w++;
+        }
+      }
+    }
+    if (w > 2147483647ll) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "PetscHipStencilRows: more than 2^31-1 entries");
+    ai[r - rstart + 1] = (PetscInt)w;
+  }
+  return 0;
+}
+
 /* PetscSplitOwnership, src/sys/utils/psplit.c:75-97 */
 extern "C" PetscErrorCode PetscSplitOwnership(PetscComm comm, PetscInt *n, PetscInt *N)
 {
@@ -697,8 +736,35 @@ extern "C" PetscErrorCode VecSetRandom(Vec x, PetscRandom rctx)
   return PetscRandomDestroy(&own);
 }
 
-extern "C" PetscErrorCode VecHipGetArrayRead(Vec v, const PetscScalar **d_a) { VecCheckReady(v, "VecHipGetArrayRead"); *d_a = v->d; return 0; }
-extern "C" PetscErrorCode VecHipGetArrayWrite(Vec v, PetscScalar **d_a) { VecCheckReady(v, "VecHipGetArrayWrite"); *d_a = v->d; v->state++; return 0; }
+/* The device pointer, for callers that launch work of their own (role of VecCUSPGetArrayRead/Write, veccusp.cu:1993-2040).  Elementwise
+   operations still waiting in the context are launched first (phip_stream flushes them), so that whatever the caller queues on
+   phip_stream(), or does after phip_sync(), sees them.  Write access: the vector's by-products are dropped when the pointer is handed
+   out and its state is bumped again when the caller gives it back (VecHipRestoreArrayWrite), as VecRestoreArray does (rvector.c:1865):
+   values cached against the old state can no longer be served while the caller writes. */
+extern "C" PetscErrorCode VecHipGetArrayRead(Vec v, const PetscScalar **d_a)
+{
+  VecCheckReady(v, "VecHipGetArrayRead");
+  if (!d_a) SETERRQ(PETSC_ERR_ARG_NULL, "VecHipGetArrayRead: null pointer");
+  (void)phip_stream(VCTX(v));
+  *d_a = v->d;
+  return 0;
+}
+extern "C" PetscErrorCode VecHipGetArrayWrite(Vec v, PetscScalar **d_a)
+{
+  VecCheckReady(v, "VecHipGetArrayWrite");
+  if (!d_a) SETERRQ(PETSC_ERR_ARG_NULL, "VecHipGetArrayWrite: null pointer");
+  (void)phip_stream(VCTX(v));
+  *d_a = v->d;
+  v->state++; v->bp.kind = 0; v->bp.live = false;
+  return 0;
+}
+extern "C" PetscErrorCode VecHipRestoreArrayWrite(Vec v, PetscScalar **d_a)
+{
+  VecCheckReady(v, "VecHipRestoreArrayWrite");
+  if (d_a) *d_a = NULL;
+  v->state++; v->bp.kind = 0; v->bp.live = false;
+  return 0;
+}
 
 extern "C" PetscErrorCode VecSetValues(Vec v, PetscInt ni, const PetscInt ix[], const PetscScalar y[], InsertMode iora)
 {
@@ -1932,6 +1998,13 @@ extern "C" PetscErrorCode MatHipGetBlockArrays(Mat A, int which, PetscInt *i, Pe
   if (diag) memcpy(diag, H.diag.data(), sizeof(PetscInt) * (size_t)H.m);
   if (H.cprow_use && cprow_i) memcpy(cprow_i, H.cprow_i.data(), sizeof(PetscInt) * H.cprow_i.size());
   if (H.cprow_use && cprow_rindex) memcpy(cprow_rindex, H.cprow_rindex.data(), sizeof(PetscInt) * H.cprow_rindex.size());
+  return 0;
+}
+extern "C" PetscErrorCode MatHipGetDeviceMat(Mat A, int which, phip_mat *dev)
+{
+  MatCheckAssembled(A, "MatHipGetDeviceMat");
+  if (!dev || which < 0 || which > 1 || (which == 1 && !A->mpi)) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "MatHipGetDeviceMat: block %d", which);
+  *dev = which ? A->B.dev : A->A.dev;
   return 0;
 }
 extern "C" PetscErrorCode MatHipGetGhostInfo(Mat A, PetscInt *ec, PetscInt *to_n, PetscInt *to_len, PetscInt *from_n)

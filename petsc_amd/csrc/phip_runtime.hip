@@ -318,6 +318,21 @@ extern "C" int phip_profile_read(phip_ctx c, int kind, int32_t *count, double *s
   return 0;
 }
 
+/* the individual durations (ms) of the launches recorded since enable, in launch order: at most cap of them are written; *count receives
+   the number recorded (bench.py: median and p10 / p90 of >= 200 timed launches) */
+extern "C" int phip_profile_durations(phip_ctx c, int kind, int32_t cap, float *h_ms, int32_t *count)
+{
+  PHIP_REQUIRE(c && count && (h_ms || cap <= 0), PHIP_ERR_ARG_NULL, "phip_profile_durations: null argument");
+  PHIP_REQUIRE(kind == 0 || kind == 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_profile_durations: kind %d", kind);
+  PHIP_NEED_DEVICE(c, "phip_profile_durations");
+  PHIP_FLUSH(c);
+  PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
+  const size_t n = c->prof ? c->prof->used[kind] : 0;
+  for (size_t k = 0; k < n && (int64_t)k < (int64_t)cap; k++) PHIP_CHECK_HIP(hipEventElapsedTime(&h_ms[k], c->prof->ev[kind][0][k], c->prof->ev[kind][1][k]));
+  *count = (int32_t)n;
+  return 0;
+}
+
 /* ---- by-product tickets -------------------------------------------------------------------------- */
 int phip_ticket_open(phip_ctx c, int nvals, int publish, phip_ticket *t, RedCtl *ctl)
 {

@@ -104,6 +104,7 @@ struct phip_mat_s {
   int32_t *d_horder; /* [n] x'[k] = x[horder[k]] */
   double  *d_hx;     /* [n] x in the hot order, refilled by every product */
   double   hot_share[2]; /* share of the gathers that fall into the hottest HOT_LINES lines of x, before / after */
+  int      nt_user;  /* phip_mat_set_nontemporal: -1 by size (default), 0 cached loads, 1 non-temporal loads of the matrix stream */
 };
 
 /* Matrix entries are read once per launch.  When the matrix is much larger than the 256 MiB Infinity Cache, non-temporal loads keep
@@ -1032,6 +1033,7 @@ extern "C" int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t
   A->h_blktpr = new std::vector<uint8_t>();
   A->h_sptr = new std::vector<int64_t>();
   A->fmt_user = g_default_fmt;
+  A->nt_user = -1;
   const int32_t *rp = use_cprow ? h_cprow_i : h_i;
   for (int32_t r = 0; r <= A->R; r++) (*A->h_rowptr)[r] = rp[r];
   if (use_cprow) {
@@ -1120,7 +1122,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     static const int dot_grid_env = getenv("PHIP_SPMV_DOT_GRID") ? atoi(getenv("PHIP_SPMV_DOT_GRID")) : 0;
     const int      dot_cap = (dot_grid_env > 0 && dot_grid_env <= PHIP_RED_BLOCKS) ? dot_grid_env : 1024;
     const unsigned grid = DOT ? (unsigned)(A->sell_nslices < dot_cap ? A->sell_nslices : dot_cap) : (unsigned)A->sell_nslices;
-    const bool     nt = 9 * A->sell_padded > PHIP_NT_MATRIX_BYTES;
+    const bool     nt = A->nt_user >= 0 ? A->nt_user != 0 : 9 * A->sell_padded > PHIP_NT_MATRIX_BYTES;
     /* results of 64 MiB and more leave with non-temporal stores: they do not push x out of the caches while the product still
        gathers from it (diagonal masks, 7-point 256^3: 97.9 -> 80.2 us, KSPCG 2759 -> 2805 it/s; 27-point 256^3: 227 -> 205 us;
        192^3, 57 MB: no change).  PHIP_SPMV_NT_Y=0|1 overrides. */
@@ -1170,7 +1172,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
       if (DOT) hipLaunchKernelGGL(dot_partials_kernel, dim3(1), dim3(DOTP_THREADS), 0, st, A->d_dotpart, A->sell_nslices, ctl);
     }
     else if (vd) {
-      const bool pnt = 4 * A->pgrp_dwords > PHIP_NT_MATRIX_BYTES;
+      const bool pnt = A->nt_user >= 0 ? A->nt_user != 0 : 4 * A->pgrp_dwords > PHIP_NT_MATRIX_BYTES;
       const int  G = pair_g_env ? pair_g_env : (A->sell_maxlen >= 16 ? 1 : 2);
 #define PAIR_LAUNCH(NTv, Gv)                                                                                                                              \
   hipLaunchKernelGGL((spmv_pair_kernel<NTv, DOT, Gv>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->m, A->sell_nslices, A->d_pptr, A->d_slen, A->d_pgrp, A->d_spoffs, \
@@ -1191,7 +1193,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     const unsigned grid = DOT ? (unsigned)(A->nblocks < dot_cap ? (A->nblocks > 0 ? A->nblocks : 1) : dot_cap) : (unsigned)A->nblocks;
     /* out-of-cache irregular matrices: non-temporal matrix stream (R-MAT scale 22: 546 -> 505 us); PHIP_CSR_NT=0/1 overrides */
     static const int csr_nt_env = getenv("PHIP_CSR_NT") ? atoi(getenv("PHIP_CSR_NT")) : -1;
-    const bool       csr_nt = csr_nt_env >= 0 ? csr_nt_env != 0 : (12 * A->nnz > PHIP_NT_MATRIX_BYTES && !A->use_cprow);
+    const bool       csr_nt = A->nt_user >= 0 ? A->nt_user != 0 : (csr_nt_env >= 0 ? csr_nt_env != 0 : (12 * A->nnz > PHIP_NT_MATRIX_BYTES && !A->use_cprow));
     const int32_t   *cols = A->d_col;
     const double    *xs = d_x;
     if (A->hot_on && A->nblocks) { /* x in the hot-column order (setup_hot) */
@@ -1370,6 +1372,18 @@ extern "C" int phip_mat_plan_get(phip_mat A, int32_t *h_block_row)
   return 0;
 }
 
+extern "C" int phip_mat_plan_lanes(phip_mat A, int64_t *h_hist)
+{
+  PHIP_REQUIRE(A && h_hist, PHIP_ERR_ARG_NULL, "phip_mat_plan_lanes: null argument");
+  for (int l = 0; l < 8; l++) h_hist[l] = 0;
+  const std::vector<int32_t> &rp = *A->h_rowptr, &br = *A->h_blkrow;
+  for (int32_t b = 0; b < A->nblocks; b++) {
+    if (rp[(size_t)br[(size_t)b + 1]] - rp[(size_t)br[(size_t)b]] > SPMV_CAP) h_hist[7]++;
+    else h_hist[(*A->h_blktpr)[(size_t)b] > 6 ? 6 : (*A->h_blktpr)[(size_t)b]]++;
+  }
+  return 0;
+}
+
 extern "C" int phip_mat_set_threads_per_row(phip_mat A, int32_t tpr)
 {
   PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_set_threads_per_row: null matrix");
@@ -1485,6 +1499,16 @@ extern "C" int phip_mat_diag_mask_info(phip_mat A, int *built, int *in_use, int3
   if (built) *built = A->dm_built;
   if (in_use) *in_use = A->dm_built && A->dm_on && A->vd_built && A->vd_on && A->sell_on;
   if (npairs) *npairs = A->dm_built ? A->dm_npairs : 0;
+  return 0;
+}
+
+/* tuning: how the kernels load the matrix stream: -1 by size (non-temporal from 192 MB on), 0 cached, 1 non-temporal; same bits */
+extern "C" int phip_mat_set_nontemporal(phip_mat A, int mode)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_set_nontemporal: null matrix");
+  PHIP_REQUIRE(mode >= -1 && mode <= 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_mat_set_nontemporal: %d (-1 by size, 0 never, 1 always)", mode);
+  A->nt_user = mode;
+  if (A->T) A->T->nt_user = mode;
   return 0;
 }
 

@@ -420,9 +420,17 @@ static int cg_update_shape(const EwBatch &B)
    matrix's masks) is.  The kernels themselves take the same time; the iteration gains: KSPCG 7-point 256^3 2335 -> 2543 it/s, 27-point
    256^3 1755 -> 1845; 7-point 192^3 (57 MB vectors) 5946 -> 6010, 128^3 (cache-resident) 16.2 k -> 15.3 k, hence the limit.
    PHIP_EW_NT=0|1 overrides. */
+static int g_ew_nt_mode = -2; /* phip_set_ew_nontemporal; -2: take PHIP_EW_NT (or the size rule) at the first launch */
+extern "C" int phip_set_ew_nontemporal(int mode)
+{
+  PHIP_REQUIRE(mode >= -1 && mode <= 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_ew_nontemporal: %d (-1 by size, 0 never, 1 always)", mode);
+  g_ew_nt_mode = mode;
+  return 0;
+}
 static inline int ew_nt(int32_t n)
 {
-  static const int env = getenv("PHIP_EW_NT") ? atoi(getenv("PHIP_EW_NT")) : -1;
+  if (g_ew_nt_mode == -2) g_ew_nt_mode = getenv("PHIP_EW_NT") ? atoi(getenv("PHIP_EW_NT")) : -1;
+  const int env = g_ew_nt_mode;
   /* cg_update_kernel also STORES X and R past the caches (bits 1 and 2 of PHIP_EW_NT_ST; nobody reads them before the next iteration,
      several cache sizes later), but not Z, which VecAYPX reads next: KSPCG it/s with stores of none / X / X,R / X,R,Z non-temporal:
      7-point 256^3 2542 / 2654 / 2759 / 2655; 27-point 256^3 1851 / 1916 / 1973 / 1924 */

@@ -31,7 +31,7 @@ _SCALAR = {"PetscInt": C.c_int32, "int32_t": C.c_int32, "int": C.c_int, "PetscBo
            "InsertMode": C.c_int, "MatAssemblyType": C.c_int, "NormType": C.c_int, "KSPNormType": C.c_int,
            "KSPGMRESCGSRefinementType": C.c_int, "PCJacobiType": C.c_int, "KSPConvergedReason": C.c_int,
            "unsigned": C.c_ulong}  # the only unsigned parameter is PetscRandomSetSeed's `unsigned long`
-_HANDLES = {"PetscComm", "Vec", "Mat", "PC", "KSP", "phip_ctx", "PetscRandom"}
+_HANDLES = {"PetscComm", "Vec", "Mat", "PC", "KSP", "phip_ctx", "phip_mat", "phip_comm", "PetscRandom"}
 
 
 def _ctype(decl):
@@ -184,6 +184,12 @@ class Comm:
     def SELF(self):
         c = Comm.__new__(Comm)
         c.h, c.rank, c.size, c.self_h, c.ctx = self.self_h, 0, 1, self.self_h, self.ctx
+        return c
+
+    def hip_comm(self):
+        """the phip_comm handle (include/petschip.h) behind this communicator"""
+        c = C.c_void_p()
+        chk(lib().PetscCommGetHipComm(self.h, C.byref(c)))
         return c
 
     def set_byproducts(self, flg):
@@ -508,6 +514,12 @@ class Mat:
         chk(lib().MatHipGetBlockArrays(self.h, which, _p(ai), _p(aj), _p(aa), _p(diag), _p(cpi), _p(cri)))
         return dict(m=m.value, n=n.value, nz=nz.value, nonzerorowcnt=nzr.value, rmax=rmax.value, cprow_use=bool(cu.value),
                     i=ai, j=aj, a=aa, diag=diag, cprow_i=cpi if cu.value else np.zeros(0, np.int32), cprow_rindex=cri)
+
+    def device_mat(self, which=0):
+        """phip_mat handle of the Seq matrix / diagonal block (0) or the off-diagonal block (1)."""
+        d = C.c_void_p()
+        chk(lib().MatHipGetDeviceMat(self.h, which, C.byref(d)))
+        return d
 
     def ghosts(self):
         ec, tn, tl, fn = [C.c_int32() for _ in range(4)]

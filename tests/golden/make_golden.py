@@ -29,55 +29,14 @@ import scipy.sparse as sp
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REF, "bin"))
+sys.path.insert(0, HERE)
 import PetscBinaryIO  # noqa: E402  (reference's reader)
 
 NAMES = ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64"]
 RAW_COPIES = ["tiny", "small", "spd-real-int32-float64"]
 
 
-def ranges(N, size):
-    n = [N // size + (1 if (N % size) > r else 0) for r in range(size)]
-    return np.concatenate([[0], np.cumsum(n)]).astype(np.int32)
-
-
-def split_products(ai, aj, N, size):
-    out = {}
-    rg = ranges(N, size)
-    out["ranges"] = rg
-    garrays = []
-    for r in range(size):
-        rs, re = int(rg[r]), int(rg[r + 1])
-        cols = aj[ai[rs]:ai[re]]
-        off = cols[(cols < rs) | (cols >= re)]
-        g = np.unique(off).astype(np.int32)
-        garrays.append(g)
-        out["garray_%d" % r] = g
-        # compact ids of the off-diagonal entries, in storage order
-        out["Bj_%d" % r] = np.searchsorted(g, off).astype(np.int32)
-        rowlen_b = np.array([np.count_nonzero((aj[ai[k]:ai[k + 1]] < rs) | (aj[ai[k]:ai[k + 1]] >= re)) for k in range(rs, re)], dtype=np.int32)
-        out["Bi_%d" % r] = np.concatenate([[0], np.cumsum(rowlen_b)]).astype(np.int32)
-    for r in range(size):
-        rs, re = int(rg[r]), int(rg[r + 1])
-        g = garrays[r]
-        owner = np.searchsorted(rg, g, side="right") - 1
-        procs, counts = np.unique(owner, return_counts=True)
-        out["from_procs_%d" % r] = procs.astype(np.int32)
-        out["from_starts_%d" % r] = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-        out["from_indices_%d" % r] = np.arange(len(g), dtype=np.int32)
-        tp, ts, ti = [], [0], []
-        for p in range(size):
-            if p == r:
-                continue
-            gp = garrays[p]
-            mine = gp[(gp >= rs) & (gp < re)] - rs
-            if len(mine):
-                tp.append(p)
-                ti.append(mine)
-                ts.append(ts[-1] + len(mine))
-        out["to_procs_%d" % r] = np.array(tp, dtype=np.int32)
-        out["to_starts_%d" % r] = np.array(ts, dtype=np.int32)
-        out["to_indices_%d" % r] = (np.concatenate(ti) if ti else np.zeros(0)).astype(np.int32)
-    return out
+from plan_numpy import ranges, split_products  # noqa: E402,F401  (numpy derivation of the MPIAIJ split products)
 
 
 def main():

@@ -1,0 +1,192 @@
+"""GPU tests of code paths that only sizes of the BASELINE benchmarks reach WITH DEFAULT SETTINGS (no knob forced): the automatic
+hot-column rule of the CSR row-block layout (x of 48 MiB and more, skewed column use), the non-temporal matrix stream of
+spmv_rowblock_kernel (matrices over 192 MB), the non-temporal loads / stores of the elementwise kernels (vectors of 48 MiB and more),
+and BASELINE config 5 as written: an R-MAT matrix in the PetscBinary format, MatLoad -> MATMPIAIJHIP on 8 ranks -> MatMult.
+Each default path is compared with the same call with the feature switched off (array-equal: the features never change a bit) and
+with a strided sample of rows / entries computed on the host (bars of BASELINE.json: SpMV <= 1e-12 relative, index work bit-exact)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_host_gpu import run_ranks  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from petsc_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def skewed_matrix(m, n, per_row, seed):
+    """m x n, per_row entries a row; column use follows a power law (u^4) and the often-used columns are scattered over the whole range"""
+    rng = np.random.default_rng(seed)
+    k = (n * rng.random((m, per_row)) ** 4).astype(np.int64)
+    cols = (k * 2654435761 + 12345) % n            # scatter the hot columns
+    cols.sort(axis=1)
+    dup = cols[:, 1:] == cols[:, :-1]
+    cols[:, 1:][dup] = np.minimum(cols[:, 1:][dup] + 1, n - 1)   # (rare) repeated columns: move on by one; a survivor is harmless
+    cols.sort(axis=1)
+    ai = (np.arange(m + 1, dtype=np.int64) * per_row).astype(np.int32)
+    return ai, cols.reshape(-1).astype(np.int32), rng.uniform(-1.0, 1.0, m * per_row)
+
+
+def test_default_hot_columns_and_nontemporal_csr(ctx):
+    """n = 6.5 M columns (x = 52 MB >= 48 MiB) and 18.2 M nonzeros (218 MB > 192 MB): phip_mat_create builds the hot-column order by its
+    own rule and the product streams the matrix with non-temporal loads, both by default."""
+    L = ctx.lib
+    m, n, per_row = 1_400_000, 6_500_000, 13
+    ai, aj, aa = skewed_matrix(m, n, per_row, 5)
+    assert 8 * n >= (48 << 20) and 12 * len(aa) > (192 << 20)
+    A = ctx.mat_create(m, n, ai, aj, aa)
+    built, used, s0, s1 = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+    ctx.check(L.phip_mat_hot_columns_info(A, C.byref(built), C.byref(used), C.byref(s0), C.byref(s1)))
+    assert built.value == 1 and used.value == 1, "the automatic rule did not build the hot-column order (shares %.3f -> %.3f)" % (s0.value, s1.value)
+    assert s1.value - s0.value >= 0.04
+    f = C.c_int()
+    ctx.check(L.phip_mat_format_info(A, C.byref(f), None, None))
+    assert f.value == 1                                             # CSR row blocks: not a stencil matrix
+    x = np.random.default_rng(6).uniform(-1.0, 1.0, n)
+    y0 = np.random.default_rng(7).uniform(-1.0, 1.0, m)
+    dx, dy, dy0 = ctx.to_device(x), ctx.to_device(np.zeros(m)), ctx.to_device(y0)
+    res = {}
+    for name, hot, nt in (("default", 1, -1), ("hot off", 0, -1), ("cached loads", 1, 0), ("both off", 0, 0)):
+        ctx.check(L.phip_mat_set_hot_columns(A, hot))
+        ctx.check(L.phip_mat_set_nontemporal(A, nt))
+        ctx.check(L.phip_mat_mult(A, dx, dy))
+        mult = ctx.to_host(dy, m)
+        ctx.check(L.phip_mat_multadd(A, dx, dy0, dy))
+        res[name] = (mult, ctx.to_host(dy, m))
+    for name in ("hot off", "cached loads", "both off"):
+        assert np.array_equal(res[name][0], res["default"][0]) and np.array_equal(res[name][1], res["default"][1]), name
+    rows = np.arange(0, m, 997)
+    ref = np.array([np.dot(aa[ai[r]:ai[r + 1]], x[aj[ai[r]:ai[r + 1]]]) for r in rows])
+    scale = np.abs(ref).max()
+    assert np.abs(res["default"][0][rows] - ref).max() <= 1e-12 * scale
+    assert np.abs(res["default"][1][rows] - (ref + y0[rows])).max() <= 1e-12 * (scale + 1.0)
+    hist = (C.c_int64 * 8)()
+    ctx.check(L.phip_mat_plan_lanes(A, hist))
+    assert sum(hist) > 0 and hist[7] == 0
+    for p in (dx, dy, dy0):
+        ctx.free(p)
+    ctx.check(L.phip_mat_destroy(A))
+
+
+def test_default_nontemporal_elementwise(ctx):
+    """vectors of 6.5 M entries (52 MB >= 48 MiB): the elementwise kernels, the batch kernel and the KSPCG batch read (and partly store)
+    past the caches by default; the same calls with the feature off must give the same bits, and the closed forms on a sample."""
+    from petsc_amd.capi import Ticket
+    L = ctx.lib
+    n = 6_500_001
+    rng = np.random.default_rng(8)
+    hx, hy, hz, hd = (rng.uniform(-1.0, 1.0, n) for _ in range(4))
+    outs = {}
+    for mode in (-1, 0):
+        ctx.check(L.phip_set_ew_nontemporal(mode))
+        x, y, z, d, w = (ctx.to_device(v) for v in (hx, hy, hz, hd, np.zeros(n)))
+        ctx.check(L.phip_vec_axpy(ctx.h, n, y, 0.75, x)); ctx.sync()                     # single launches (ew_kernel)
+        ctx.check(L.phip_vec_aypx(ctx.h, n, z, -0.5, x)); ctx.sync()
+        ctx.check(L.phip_vec_waxpy(ctx.h, n, w, 1.25, x, y)); ctx.sync()
+        r1 = [ctx.to_host(p, n) for p in (y, z, w)]
+        tk = Ticket()                                                                    # the KSPCG batch (cg_update_kernel)
+        ctx.check(L.phip_vec_axpy(ctx.h, n, x, 1e-3, z))
+        ctx.check(L.phip_vec_axpy(ctx.h, n, y, -1e-3, w))
+        ctx.check(L.phip_vec_pointwise_mult_reduce(ctx.h, n, w, d, y, 1, C.byref(tk)))
+        sums = (C.c_double * 3)()
+        ctx.check(L.phip_ticket_wait(ctx.h, C.byref(tk), sums))
+        r2 = [ctx.to_host(p, n) for p in (x, y, w)]
+        outs[mode] = (r1, r2, list(sums))
+        for p in (x, y, z, d, w):
+            ctx.free(p)
+    ctx.check(L.phip_set_ew_nontemporal(-1))
+    for a, b in zip(outs[-1][0] + outs[-1][1], outs[0][0] + outs[0][1]):
+        assert np.array_equal(a, b)
+    assert outs[-1][2] == outs[0][2]
+    s = np.arange(0, n, 4099)
+    y1 = hy[s] + 0.75 * hx[s]
+    z1 = hx[s] + -0.5 * hz[s]
+    w1 = y1 + 1.25 * hx[s]
+    for got, want in zip(outs[-1][0], (y1, z1, w1)):
+        assert np.abs(got[s] - want).max() <= 4e-16 * np.abs(want).max()
+    x2 = hx[s] + 1e-3 * z1
+    y2 = y1 + -1e-3 * w1
+    w2 = hd[s] * y2
+    for got, want in zip(outs[-1][1], (x2, y2, w2)):
+        assert np.abs(got[s] - want).max() <= 1e-15 * np.abs(want).max()
+
+
+def read_petscbin_mat(path):
+    """the PetscBinary Mat format of MatView_SeqAIJ_Binary (aij.c:547-582), parsed with numpy alone"""
+    raw = np.fromfile(path, dtype=">i4", count=4)
+    assert raw[0] == 1211216
+    M, N, nz = int(raw[1]), int(raw[2]), int(raw[3])
+    lens = np.fromfile(path, dtype=">i4", count=M, offset=16).astype(np.int64)
+    aj = np.fromfile(path, dtype=">i4", count=nz, offset=16 + 4 * M).astype(np.int32)
+    aa = np.fromfile(path, dtype=">f8", count=nz, offset=16 + 4 * M + 4 * nz).astype(np.float64)
+    ai = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    return M, N, ai, aj, aa
+
+
+@pytest.mark.parametrize("size", [1, 8])
+def test_rmat16_matload_mpiaij(orc, golden_dir, size):
+    """BASELINE config 5 at the committed scale (2^16 rows, 955 094 nonzeros, written by the reference's PetscBinaryIO.py): MatLoad
+    (mpiaij.c:2890-3089: row split m = M/size + ((M % size) > rank)) into MATMPIAIJHIP on 8 ranks, MatMult against the oracle's
+    MatMult_MPIAIJ and against scipy's result stored with the fixture; garray and the scatter plan array-equal to their numpy
+    derivation; per-rank nonzeros and the row-binning histogram of both blocks reported."""
+    from petsc_amd import capi, petsc as P
+    sys.path.insert(0, golden_dir)
+    import plan_numpy
+    src = os.path.join(golden_dir, "rmat16.petscbin")
+    exp = np.load(os.path.join(golden_dir, "rmat16_expect.npz"), allow_pickle=False)
+    M, N, ai, aj, aa = read_petscbin_mat(src)
+    assert (M, N, len(aa)) == (int(exp["M"]), int(exp["N"]), int(exp["nz"]))
+    xg = exp["x"]
+    plan = plan_numpy.split_products(ai, aj, N, size) if size > 1 else None
+    L = capi.load()
+
+    def body(comm):
+        A = P.Mat(comm)
+        A.load(src)
+        assert A.type() == ("mpiaijhip" if size > 1 else "seqaijhip") and A.sizes()[2:] == (M, N)
+        rs, re = A.ownership_range()
+        x = P.Vec.from_array(comm, xg[rs:re], N)
+        y = x.duplicate()
+        A.mult(x, y)
+        out = {"y": y.array(), "range": (rs, re), "nnz": A.block(0)["nz"] + (A.block(1)["nz"] if size > 1 else 0), "hist": []}
+        for which in range(2 if size > 1 else 1):
+            h = (C.c_int64 * 8)()
+            assert L.phip_mat_plan_lanes(A.device_mat(which), h) == 0
+            out["hist"].append(list(h))
+        if size > 1:
+            gh, r = A.ghosts(), comm.rank
+            np.testing.assert_array_equal(gh["garray"], plan["garray_%d" % r])
+            for key in ("from_procs", "from_starts", "to_procs", "to_starts", "to_indices"):
+                np.testing.assert_array_equal(gh[key], plan["%s_%d" % (key, r)], err_msg=key)
+            blkB = A.block(1)
+            np.testing.assert_array_equal(blkB["j"], plan["Bj_%d" % r])
+            np.testing.assert_array_equal(blkB["i"], plan["Bi_%d" % r])
+        for o in (x, y, A):
+            o.destroy()
+        return out
+
+    res = run_ranks(size, body)
+    y = np.concatenate([r["y"] for r in res])
+    scale = np.abs(exp["y"]).max()
+    assert np.abs(y - exp["y"]).max() <= 1e-12 * scale                                   # scipy csr_matvec, stored with the fixture
+    yo = orc.operator(ai, aj, aa, size).mult(xg)                                          # MatMult_MPIAIJ restated: A x then B lvec added
+    assert np.abs(y - yo).max() <= 1e-12 * scale
+    rg = plan_numpy.ranges(M, size)
+    assert [r["range"] for r in res] == [(int(rg[k]), int(rg[k + 1])) for k in range(size)]
+    nnz = [r["nnz"] for r in res]
+    assert sum(nnz) == len(aa) and all(sum(h) > 0 for r in res for h in r["hist"])       # every block has a non-empty binning histogram
+    if size == 8:
+        np.testing.assert_array_equal(nnz, exp["nnz_rank8"])
+        print("rmat16 over 8 ranks: nnz per rank %s, imbalance %.2f; lanes-per-row histogram of rank 0's diagonal block %s"
+              % (nnz, max(nnz) / (sum(nnz) / 8.0), res[0]["hist"][0]))

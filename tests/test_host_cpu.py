@@ -196,3 +196,15 @@ def test_mpiaij_plan_shm(world, name, mode):
     """The same index work with the library's own multi-process communicator (backend "shm": shared-memory ring) carrying the
     handshake -- the host side of what bench.py runs with under torch.distributed.run."""
     _run_world(world, name, mode, comm="shm")
+
+
+def test_native_stencil_generator_matches_numpy():
+    """bench.py builds its matrices with the C loop of the host library (PetscHipStencilRows); the numpy generators the parity tests use
+    must give the same arrays, for whole matrices and for the row ranges the ranks of a multi-GPU run ask for."""
+    from petsc_amd import generators as G
+    for kind, fn in ((7, lambda a, b: G.laplace3d_7pt(9, 7, 11, rstart=a, rend=b, dirichlet_rows=False)), (27, lambda a, b: G.box3d_27pt(9, 7, 11, rstart=a, rend=b))):
+        for a, b in ((0, None), (100, 433), (0, 0), (692, 693)):
+            for u, v in zip(fn(a, b), G.stencil_rows_native(kind, 9, 7, 11, a, b)):
+                np.testing.assert_array_equal(u, v)
+    for u, v in zip(G.laplace2d_5pt(13, 17), G.stencil_rows_native(5, 17, 13, 1)):
+        np.testing.assert_array_equal(u, v)
