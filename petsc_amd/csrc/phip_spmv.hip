@@ -90,9 +90,11 @@ struct phip_mat_s {
   int       dm_built, dm_on;
   int32_t   dm_npairs;
   uint32_t *d_rmask;  /* [S * 512] bit q of rmask[r]: row r holds pair q */
-  double   *d_dotpart; /* [S] the fused dot's partial sum of each slice (full-grid variant, see launch_spmv_t) */
+  double   *d_dotpart; /* [4 S] the fused dot's partial sum of each wave (spmv_dmask_kernel<DOT>, summed by dot_wave_partials_kernel) */
   int32_t  *d_dmoffs; /* [32] */
   double   *d_dmvals; /* [32] */
+  int32_t  *d_dmgrp;  /* [dm_ngroups][4]: groups of pairs whose diagonals lie within DM4_SPAN of each other: {base diagonal, set of its pairs, span, 0} */
+  int32_t   dm_ngroups;
   std::vector<uint8_t> *h_scode; /* host copies of scode and soffs: phip_mat_update_values rebuilds the pairs from them */
   std::vector<int32_t> *h_soffs;
   /* operator of y = A^T x: a second matrix holding A^T row by row, built on request (phip_mat_transpose_setup) */
@@ -461,7 +463,6 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmask_kernel(int32_t m, int
                                                                   int add, const double *__restrict__ dotv, double *__restrict__ wgpart, RedCtl ctl, int nty)
 {
 #pragma clang fp contract(off)
-  __shared__ double lds[4];
   const int t = threadIdx.x;
   double    dacc = 0.0;
   for (int b = blockIdx.x; b < nslices; b += gridDim.x) {
@@ -472,7 +473,10 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmask_kernel(int32_t m, int
     double yA = 0.0, yB = 0.0;
     if (add) { if (actA) yA = yin[r0]; if (actB) yB = yin[r0 + 1]; }
     double dvA = 0.0, dvB = 0.0;
-    if (DOT) { if (actA) dvA = dotv[r0]; if (actB) dvB = dotv[r0 + 1]; }
+    if (DOT) { /* the fused dot's weights, one 16-byte load for the lane's two rows */
+      if (actB) { const phip_v2d_u q = *reinterpret_cast<const phip_v2d_u *>(dotv + r0); dvA = q.x; dvB = q.y; }
+      else if (actA) dvA = dotv[r0];
+    }
     double sA = yA, sB = yB;
     /* the pairs some row of this wave holds */
     uint32_t um = mA | mB;
@@ -520,47 +524,183 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmask_kernel(int32_t m, int
       if (actB) dacc += dvB * (sB - yB);
     }
   }
-  if (DOT) {
-    double a1[1] = {dacc};
-    block_sum<1>(a1, lds);
-    if (wgpart) { /* one workgroup per slice: the partial waits for dot_partials_kernel */
-      if (t == 0) wgpart[blockIdx.x] = a1[0];
-      return;
-    }
-    __syncthreads();
-    reduce_tail<1, 0>(a1, lds, ctl);
+  if (DOT) { /* one partial per WAVE, stored and forgotten: no barrier, no wave waits for anything (dot_wave_partials_kernel sums them) */
+    const double s = wave_sum(dacc);
+    if ((t & 63) == 0) wgpart[(size_t)blockIdx.x * (PHIP_THREADS / 64) + (t >> 6)] = s;
   }
 }
 
-/* second half of the fused dot when the product ran one workgroup per slice: nb partials, summed in a fixed order (thread t of 1024
-   adds the entries t, t + 1024, ...; then the wave trees and the 16 wave sums in order) and published as reduce_tail publishes */
-#define DOTP_THREADS 1024
-__global__ __launch_bounds__(DOTP_THREADS) void dot_partials_kernel(const double *__restrict__ part, int nb, RedCtl c)
+/* The diagonal masks with FOUR adjacent rows per lane and the pairs taken in GROUPS of neighbouring diagonals.  spmv_dmask_kernel above
+   still pushes every x entry through the vector L1 once per diagonal that touches it (27 times for a 27-point stencil): 216 B per row,
+   and the 64 B/clock/CU of that path, not HBM, is what its 205 us at 27-point 256^3 are made of (HBM traffic: 335 MB).  Neighbouring
+   rows use neighbouring entries, and neighbouring diagonals use them again: the rows r .. r+3 of a lane need, for the diagonals
+   D, D+1, D+2 of one group, just x[r+D .. r+D+5] -- three 16-byte loads instead of six (two rows a lane, one diagonal a load).  The
+   window stays in registers while the group's pairs are worked off in ascending diagonal order, so a row still adds its products
+   k-ascending with separately rounded multiply and add: the same bits.  A group whose pairs share one diagonal loads four entries (two
+   loads).  Waves whose windows could leave x (first and last rows, far diagonals) load entry by entry with clamped indices; an entry
+   outside the row's own pairs is never used.  UG groups are requested before the sums of the first begin.  One workgroup = 1024 rows. */
+#define DMASK_MAX_PAIRS 32
+#define DM4_ROWS 4
+#define DM4_SPAN 3 /* diagonals D .. D + DM4_SPAN - 1 share a window of DM4_ROWS + DM4_SPAN - 1 entries */
+#define DM4_WIN (DM4_ROWS + DM4_SPAN - 1)
+
+template <int OFF>
+__device__ __forceinline__ void dm4_step(double (&s)[DM4_ROWS], const double (&w)[DM4_WIN], double v, const uint32_t (&mk)[DM4_ROWS], int q)
 {
-  __shared__ double lds[DOTP_THREADS / 64];
-  const int t = threadIdx.x;
-  double    s = 0.0;
-  int       i = t;
-  for (; i + 15 * DOTP_THREADS < nb; i += 16 * DOTP_THREADS) { /* sixteen loads in flight, added in index order */
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < DM4_ROWS; i++)
+    if ((mk[i] >> q) & 1u) s[i] = s[i] + v * w[i + OFF];
+}
+
+/* the same for a pair that EVERY row of the wave holds: no tests, no selects (a third of the instructions) */
+template <int OFF>
+__device__ __forceinline__ void dm4_step_all(double (&s)[DM4_ROWS], const double (&w)[DM4_WIN], double v)
+{
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < DM4_ROWS; i++) s[i] = s[i] + v * w[i + OFF];
+}
+
+template <bool DOT, bool ADD, int UG>
+__global__ __launch_bounds__(PHIP_THREADS) void spmv_dmask4_kernel(int32_t m, int32_t n, const uint32_t *__restrict__ rmask, const int32_t *__restrict__ poffs,
+                                                                   const double *__restrict__ pvals, const int4 *__restrict__ gtab, int ngroups,
+                                                                   const double *__restrict__ x, const double *__restrict__ yin, double *__restrict__ yout,
+                                                                   const double *__restrict__ dotv, double *__restrict__ wavepart, int nty)
+{
+#pragma clang fp contract(off)
+  const int      t = threadIdx.x;
+  const int      r0 = (int)blockIdx.x * (PHIP_THREADS * DM4_ROWS) + DM4_ROWS * t;
+  const uint4    mq = reinterpret_cast<const uint4 *>(rmask)[(size_t)blockIdx.x * PHIP_THREADS + t]; /* the mask array is padded to whole workgroups */
+  const uint32_t mk[DM4_ROWS] = {mq.x, mq.y, mq.z, mq.w};
+  const int      nact = m - r0; /* rows r0 .. r0 + 3 exist while i < nact */
+  double         y0[DM4_ROWS] = {0.0, 0.0, 0.0, 0.0}, s[DM4_ROWS], dv[DM4_ROWS] = {0.0, 0.0, 0.0, 0.0};
+  if (ADD) {
+    if (nact >= DM4_ROWS) {
+      const phip_v2d_u a = *reinterpret_cast<const phip_v2d_u *>(yin + r0), b = *reinterpret_cast<const phip_v2d_u *>(yin + r0 + 2);
+      y0[0] = a.x; y0[1] = a.y; y0[2] = b.x; y0[3] = b.y;
+    } else {
+#pragma unroll
+      for (int i = 0; i < DM4_ROWS; i++) if (i < nact) y0[i] = yin[r0 + i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DM4_ROWS; i++) s[i] = y0[i];
+  uint32_t um = mk[0] | mk[1] | mk[2] | mk[3];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) um |= (uint32_t)__shfl_xor((int)um, o, 64);
+  const uint32_t rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)um); /* the pairs some row of this wave holds */
+  uint32_t am = mk[0] & mk[1] & mk[2] & mk[3];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) am &= (uint32_t)__shfl_xor((int)am, o, 64);
+  const uint32_t uni = (uint32_t)__builtin_amdgcn_readfirstlane((int)am); /* the pairs EVERY row of this wave holds */
+  const int      w0 = (int)blockIdx.x * (PHIP_THREADS * DM4_ROWS) + (t & ~63) * DM4_ROWS; /* first of the 256 rows of this wave */
+  /* the group table and the pair table live in the lanes of the wave (entry l in lane l) and are read with v_readlane: no memory
+     latency inside the loops below */
+  const int  lane = t & 63;
+  const int4 gl = lane < ngroups ? gtab[lane] : make_int4(0, 0, 1, 0);
+  const int    pl_off = lane < DMASK_MAX_PAIRS ? poffs[lane] : 0;
+  const double pl_val = lane < DMASK_MAX_PAIRS ? pvals[lane] : 0.0;
+  const int    pl_lo = __double2loint(pl_val), pl_hi = __double2hiint(pl_val);
+  int          gi = 0;
+  while (gi < ngroups) {
+    int      gD[UG], gS[UG];
+    uint32_t gM[UG];
+#pragma unroll
+    for (int u = 0; u < UG; u++) { /* the next UG groups that some row of the wave takes part in */
+      gM[u] = 0u; gD[u] = 0; gS[u] = 1;
+      while (gi < ngroups) {
+        const uint32_t set = (uint32_t)__builtin_amdgcn_readlane(gl.y, gi);
+        if (set & rem) { gD[u] = __builtin_amdgcn_readlane(gl.x, gi); gS[u] = __builtin_amdgcn_readlane(gl.z, gi); gM[u] = set & rem; gi++; break; }
+        gi++;
+      }
+    }
+    double w[UG][DM4_WIN];
+#pragma unroll
+    for (int u = 0; u < UG; u++) {
+#pragma unroll
+      for (int j = 0; j < DM4_WIN; j++) w[u][j] = 0.0;
+      if (gM[u]) {
+        const int D = gD[u];
+        if ((int64_t)w0 + D >= 0 && (int64_t)w0 + 64 * DM4_ROWS - 1 + D + (DM4_SPAN - 1) < (int64_t)n) { /* the wave's windows stay inside x */
+          const double     *p = x + ((int64_t)r0 + D);
+          const phip_v2d_u  a = *reinterpret_cast<const phip_v2d_u *>(p), b = *reinterpret_cast<const phip_v2d_u *>(p + 2);
+          w[u][0] = a.x; w[u][1] = a.y; w[u][2] = b.x; w[u][3] = b.y;
+          if (gS[u] > 1) { const phip_v2d_u c = *reinterpret_cast<const phip_v2d_u *>(p + 4); w[u][4] = c.x; w[u][5] = c.y; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < DM4_WIN; j++) {
+            int64_t k = (int64_t)r0 + D + j;
+            k = k < 0 ? 0 : (k >= (int64_t)n ? (int64_t)n - 1 : k);
+            w[u][j] = x[k];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UG; u++) {
+      uint32_t gm = gM[u];
+      while (gm) {
+        const int q = __builtin_ctz(gm);
+        gm &= gm - 1;
+        const int    off = __builtin_amdgcn_readlane(pl_off, q) - gD[u];
+        const double v = __hiloint2double(__builtin_amdgcn_readlane(pl_hi, q), __builtin_amdgcn_readlane(pl_lo, q));
+        if ((uni >> q) & 1u) {
+          if (off == 0) dm4_step_all<0>(s, w[u], v);
+          else if (off == 1) dm4_step_all<1>(s, w[u], v);
+          else dm4_step_all<2>(s, w[u], v);
+        } else {
+          if (off == 0) dm4_step<0>(s, w[u], v, mk, q);
+          else if (off == 1) dm4_step<1>(s, w[u], v, mk, q);
+          else dm4_step<2>(s, w[u], v, mk, q);
+        }
+      }
+    }
+  }
+  if (nact >= DM4_ROWS) {
+    st_result2(yout + r0, s[0], s[1], nty);
+    st_result2(yout + r0 + 2, s[2], s[3], nty);
+  } else {
+#pragma unroll
+    for (int i = 0; i < DM4_ROWS; i++) if (i < nact) yout[r0 + i] = s[i];
+  }
+  if (DOT) { /* one partial per wave, stored and forgotten (dot_wave_partials_kernel sums them).  The weights are requested only now:
+                held across the loop they cost 24 VGPRs and a sixth of the occupancy; the entries were gathered a moment ago (CG: dotv = x) */
+    if (nact >= DM4_ROWS) {
+      const phip_v2d_u a = *reinterpret_cast<const phip_v2d_u *>(dotv + r0), b = *reinterpret_cast<const phip_v2d_u *>(dotv + r0 + 2);
+      dv[0] = a.x; dv[1] = a.y; dv[2] = b.x; dv[3] = b.y;
+    } else {
+#pragma unroll
+      for (int i = 0; i < DM4_ROWS; i++) if (i < nact) dv[i] = dotv[r0 + i];
+    }
+    double dacc = 0.0;
+#pragma unroll
+    for (int i = 0; i < DM4_ROWS; i++) if (i < nact) dacc += dv[i] * (ADD ? s[i] - y0[i] : s[i]); /* MultAdd: the increment A x, not z */
+    dacc = wave_sum(dacc);
+    if ((t & 63) == 0) wavepart[(size_t)blockIdx.x * (PHIP_THREADS / 64) + (t >> 6)] = dacc;
+  }
+}
+
+/* second half of the fused dot of spmv_dmask_kernel: np wave partials, summed in a fixed order (thread t of workgroup b adds the entries
+   (b * 256 + t) + k * gridDim.x * 256, k ascending, sixteen loads in flight; then block_sum and reduce_tail) and delivered as
+   reduce_tail delivers */
+__global__ __launch_bounds__(PHIP_THREADS) void dot_wave_partials_kernel(const double *__restrict__ part, int np, RedCtl c)
+{
+  __shared__ double lds[4];
+  const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
+  double        a1[1] = {0.0};
+  int64_t       i = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x;
+  for (; i + 15 * stride < np; i += 16 * stride) {
     double p[16];
 #pragma unroll
-    for (int u = 0; u < 16; u++) p[u] = part[i + u * DOTP_THREADS];
+    for (int u = 0; u < 16; u++) p[u] = part[i + u * stride];
 #pragma unroll
-    for (int u = 0; u < 16; u++) s += p[u];
+    for (int u = 0; u < 16; u++) a1[0] += p[u];
   }
-  for (; i < nb; i += DOTP_THREADS) s += part[i];
-  s = wave_sum(s);
-  if ((t & 63) == 0) lds[t >> 6] = s;
+  for (; i < np; i += stride) a1[0] += part[i];
+  block_sum<1>(a1, lds);
   __syncthreads();
-  if (t == 0) {
-    double a = 0.0;
-#pragma unroll
-    for (int w = 0; w < DOTP_THREADS / 64; w++) a += lds[w];
-    const double r = c.accumulate ? c.d_out[c.kofs] + a : a;
-    c.d_out[c.kofs] = r;
-    if (c.h_ll && c.kofs < c.npub) publish_ll(c.h_ll, c.kofs, r, c.seq);
-  }
-  if (c.h_ll && t < c.kofs && t < c.npub) publish_ll(c.h_ll, t, c.d_out[t], c.seq);
+  reduce_tail<1, 0>(a1, lds, c);
 }
 
 __global__ void getdiag_kernel(int32_t m, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx, int32_t R,
@@ -809,14 +949,13 @@ static void free_pairs(phip_mat A)
 
 static void free_dmask(phip_mat A)
 {
-  if (A->ctx->device >= 0) { hipFree(A->d_rmask); hipFree(A->d_dmoffs); hipFree(A->d_dmvals); hipFree(A->d_dotpart); }
-  A->d_rmask = NULL; A->d_dmoffs = NULL; A->d_dmvals = NULL; A->d_dotpart = NULL; A->dm_built = 0; A->dm_on = 0; A->dm_npairs = 0;
+  if (A->ctx->device >= 0) { hipFree(A->d_rmask); hipFree(A->d_dmoffs); hipFree(A->d_dmvals); hipFree(A->d_dotpart); hipFree(A->d_dmgrp); }
+  A->d_rmask = NULL; A->d_dmoffs = NULL; A->d_dmvals = NULL; A->d_dotpart = NULL; A->d_dmgrp = NULL; A->dm_ngroups = 0; A->dm_built = 0; A->dm_on = 0; A->dm_npairs = 0;
 }
 
 /* diagonal-mask layout out of the pair codes (slot-major bytes, laid out like scode).  Not built when there are more than 32 pairs or
    when some row does not meet its pairs in strictly ascending diagonal order (unsorted or repeated columns): such a row's k-ascending
    sum is not the ascending-diagonal sum. */
-#define DMASK_MAX_PAIRS 32
 static int g_dm_mode = -1;
 static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std::vector<int32_t> &poffs, const std::vector<double> &pvals, int npairs)
 {
@@ -828,7 +967,7 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
   std::stable_sort(order, order + npairs, [&](int a, int b) { return poffs[(size_t)a] < poffs[(size_t)b]; });
   for (int q = 0; q < npairs; q++) rank[order[q]] = q;
   const int32_t         S = A->sell_nslices;
-  std::vector<uint32_t> rmask((size_t)S * SELL_H + 2, 0u);
+  std::vector<uint32_t> rmask((size_t)S * SELL_H + PHIP_THREADS * DM4_ROWS + 2, 0u); /* padded to whole workgroups of spmv_dmask4_kernel */
   const std::vector<int32_t> &rp = *A->h_rowptr;
   for (int32_t r = 0; r < A->m; r++) {
     const int32_t b = r / SELL_H;
@@ -848,16 +987,30 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
   int32_t offs[DMASK_MAX_PAIRS] = {0};
   double  vals[DMASK_MAX_PAIRS] = {0.0};
   for (int q = 0; q < npairs; q++) { offs[q] = poffs[(size_t)order[q]]; vals[q] = pvals[(size_t)order[q]]; }
+  /* groups of pairs whose diagonals lie within DM4_SPAN of the group's first (spmv_dmask4_kernel): {base diagonal, pair set, span, 0} */
+  int32_t grp[DMASK_MAX_PAIRS][4];
+  int     ngroups = 0;
+  for (int q = 0; q < npairs;) {
+    const int32_t D = offs[q];
+    uint32_t      set = 0;
+    int32_t       span = 1;
+    while (q < npairs && (int64_t)offs[q] - D < DM4_SPAN) { set |= 1u << q; span = offs[q] - D + 1; q++; }
+    grp[ngroups][0] = D; grp[ngroups][1] = (int32_t)set; grp[ngroups][2] = span; grp[ngroups][3] = 0;
+    ngroups++;
+  }
+  A->dm_ngroups = ngroups;
   hipStream_t st = A->ctx->stream;
   if (!A->d_rmask) {
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dmgrp, sizeof(grp)));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rmask, sizeof(uint32_t) * rmask.size()));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dmoffs, sizeof(offs)));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dmvals, sizeof(vals)));
-    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dotpart, sizeof(double) * ((size_t)S + 1)));
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dotpart, sizeof(double) * ((size_t)S * (PHIP_THREADS / 64) + 2)));
   }
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_rmask, rmask.data(), sizeof(uint32_t) * rmask.size(), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmoffs, offs, sizeof(offs), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmvals, vals, sizeof(vals), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmgrp, grp, sizeof(grp), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipStreamSynchronize(st));
   A->dm_built = 1; A->dm_on = was_on; A->dm_npairs = npairs;
   return 0;
@@ -1153,23 +1306,44 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
        capped grid a workgroup walks several slices one after the other, each starting with its serial prologue (masks, wave-wide
        OR), and loses what the wider loads give (7-point 128^3 inside KSPCG 20.8 -> 23.2 us at 1024 workgroups; 27-point 192^3: 136 us
        at 4096 workgroups against 90 us for the plain product).  So the fused dot runs like the plain product, one workgroup per
-       slice, leaves one partial per slice, and a one-workgroup kernel right behind it sums and publishes them
-       (dot_partials_kernel): deterministic, and the product keeps its speed.  The second launch costs ~2 us, so small matrices keep
-       the single-launch pair-code kernel for the fused dot.  KSPCG it/s, masks against pair codes: 7-point 128^3 15.4 k / 16.2 k,
-       192^3 5671 / 5602, 256^3 2294 / 2268; 27-point 128^3 11.90 k / 11.71 k, 192^3 4188 / 3707, 256^3 1741 / 1579 -- the masks from
-       40 M nonzeros on.  PHIP_DMASK_DOT=0|1 overrides. */
+       slice; every WAVE leaves one partial with a plain store and ends -- no barrier, nothing waits -- and a small kernel right
+       behind it sums the partials in a fixed order and publishes (dot_wave_partials_kernel): deterministic.  What a fused dot must
+       not do in a kernel of many short workgroups is hold them: one partial per workgroup (LDS, barrier) with the reduce_tail code
+       in the kernel cost 75 instead of 46 VGPRs and 27-point 256^3 ran 271 us against 205 us plain; arrival counters in the kernel
+       (write-through store, wait, atomic with return: ~4 us per workgroup) the same, and 7-point 128^3 27 us against 13.6 us.
+       PHIP_DMASK_DOT=0 sends the fused-dot products to the pair-code kernel instead (round 1's rule for matrices under 40 M nonzeros;
+       with four rows a lane the masks win there too: 7-point 128^3 fused-dot product 13.9 us against 16.1 us). */
     static const int dm_u_env = getenv("PHIP_DMASK_UNROLL") ? atoi(getenv("PHIP_DMASK_UNROLL")) : 0;
     static const int dm_dot_env = getenv("PHIP_DMASK_DOT") ? atoi(getenv("PHIP_DMASK_DOT")) : -1;
-    if (vd && A->dm_built && A->dm_on && (!DOT || g_dm_mode == 2 || (dm_dot_env >= 0 ? dm_dot_env != 0 : A->nnz >= 40000000))) {
-      const unsigned dgrid = (unsigned)A->sell_nslices;
+    if (vd && A->dm_built && A->dm_on && (!DOT || g_dm_mode == 2 || dm_dot_env != 0)) {
       double        *part = DOT ? A->d_dotpart : NULL;
-      if (dm_u_env == 8)
-        hipLaunchKernelGGL((spmv_dmask_kernel<DOT, 8>), dim3(dgrid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_rmask, A->d_dmoffs, A->d_dmvals, d_x,
-                           d_yin, d_yout, add, d_v, part, ctl, nty);
-      else
-        hipLaunchKernelGGL((spmv_dmask_kernel<DOT, 4>), dim3(dgrid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_rmask, A->d_dmoffs, A->d_dmvals, d_x,
-                           d_yin, d_yout, add, d_v, part, ctl, nty);
-      if (DOT) hipLaunchKernelGGL(dot_partials_kernel, dim3(1), dim3(DOTP_THREADS), 0, st, A->d_dotpart, A->sell_nslices, ctl);
+      /* four rows a lane and grouped diagonals (spmv_dmask4_kernel) unless PHIP_DMASK_ROWS=2 asks for the two-row kernel */
+      static const int dm_rows_env = getenv("PHIP_DMASK_ROWS") ? atoi(getenv("PHIP_DMASK_ROWS")) : 4;
+      static const int dm_ug_env = getenv("PHIP_DMASK_GROUPS") ? atoi(getenv("PHIP_DMASK_GROUPS")) : 0;
+      int              nwg;
+      if (dm_rows_env != 2) {
+        nwg = (A->m + PHIP_THREADS * DM4_ROWS - 1) / (PHIP_THREADS * DM4_ROWS);
+        const int ug = dm_ug_env ? dm_ug_env : 1; /* 27-point 256^3: 1 / 2 / 3 / 4 groups in flight 121.6 / 126.6 / 133.0 / 147.3 us: occupancy hides the latency better */
+#define DM4_LAUNCH(ADDv, UGv)                                                                                                                             \
+  hipLaunchKernelGGL((spmv_dmask4_kernel<DOT, ADDv, UGv>), dim3((unsigned)nwg), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->d_rmask, A->d_dmoffs, A->d_dmvals, \
+                     reinterpret_cast<const int4 *>(A->d_dmgrp), A->dm_ngroups, d_x, d_yin, d_yout, d_v, part, nty)
+        if (add) { if (ug == 2) DM4_LAUNCH(true, 2); else DM4_LAUNCH(true, 1); }
+        else { if (ug == 2) DM4_LAUNCH(false, 2); else DM4_LAUNCH(false, 1); }
+#undef DM4_LAUNCH
+      } else {
+        nwg = A->sell_nslices;
+        const unsigned dgrid = (unsigned)A->sell_nslices;
+        if (dm_u_env == 8)
+          hipLaunchKernelGGL((spmv_dmask_kernel<DOT, 8>), dim3(dgrid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_rmask, A->d_dmoffs, A->d_dmvals, d_x,
+                             d_yin, d_yout, add, d_v, part, ctl, nty);
+        else
+          hipLaunchKernelGGL((spmv_dmask_kernel<DOT, 4>), dim3(dgrid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_rmask, A->d_dmoffs, A->d_dmvals, d_x,
+                             d_yin, d_yout, add, d_v, part, ctl, nty);
+      }
+      if (DOT) { /* 16 entries per thread and round: 27-point 256^3 has 131 072 wave partials = 32 workgroups */
+        const int np = nwg * (PHIP_THREADS / 64);
+        hipLaunchKernelGGL(dot_wave_partials_kernel, dim3(phip_grid_for(np, 16, PHIP_RED_GRID)), dim3(PHIP_THREADS), 0, st, A->d_dotpart, np, ctl);
+      }
     }
     else if (vd) {
       const bool pnt = A->nt_user >= 0 ? A->nt_user != 0 : 4 * A->pgrp_dwords > PHIP_NT_MATRIX_BYTES;
