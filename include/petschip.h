@@ -166,6 +166,19 @@ int phip_set_default_hot_columns(int mode);
 int phip_mat_set_hot_columns(phip_mat A, int on);
 int phip_mat_hot_columns_info(phip_mat A, int *built, int *in_use, double *share_before, double *share_after);
 
+/* Hot columns resident in LDS, for the same kind of matrix (CSR row-block layout, columns used very unevenly): the K most used
+ * columns (K = what 127 KiB of LDS hold, about 16 000) are copied from x into LDS by every workgroup of a persistent kernel (one
+ * 1024-thread workgroup per CU) and gathered from there; a WAVE owns a block of rows (<= 254 nonzeros, <= 64 rows), sums each row with
+ * 1..64 lanes out of an LDS stage of its own (one lane per row: k-ascending from 0.0 or y[i], the reference's bits).  A scattered
+ * gather from LDS costs a wave a few clocks, from the caches about 3 clocks per lane.  EXPERIMENTAL AND OFF BY DEFAULT: exact, but on
+ * R-MAT it is slower than the row-block kernel (16 waves per CU hide too little latency; very long rows are walked by one wave; numbers in
+ * DESIGN.md).  PHIP_LDS_HOT or phip_set_default_lds_hot: 0 never (default), 1 build at phip_mat_create for matrices of 2^20 nonzeros and
+ * more whose K columns carry >= 10 % of the nonzeros, 2 whenever there are nonzeros; phip_mat_set_lds_hot switches between this kernel
+ * and the row-block kernel. */
+int phip_set_default_lds_hot(int mode);
+int phip_mat_set_lds_hot(phip_mat A, int on);
+int phip_mat_lds_hot_info(phip_mat A, int *built, int *in_use, int32_t *K, double *share);
+
 /* ---- vector kernels (the _VecOps slots, include/petsc/private/vecimpl.h:20-96) --------------------
  * n = local length.  Results of reductions are written to host memory and are valid on return.
  * The elementwise operations (axpy ... reciprocal, set) are asynchronous like every launch, and in addition DEFERRED: they wait in the

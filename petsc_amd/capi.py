@@ -60,6 +60,9 @@ SIGNATURES = [
     ("phip_set_default_hot_columns", C.c_int, [C.c_int]),
     ("phip_mat_set_hot_columns", C.c_int, [_vp, C.c_int]),
     ("phip_mat_hot_columns_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pD, _pD]),
+    ("phip_set_default_lds_hot", C.c_int, [C.c_int]),
+    ("phip_mat_set_lds_hot", C.c_int, [_vp, C.c_int]),
+    ("phip_mat_lds_hot_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pI, _pD]),
     ("phip_vec_dot", C.c_int, [_vp, C.c_int32, _vp, _vp, _pD]),
     ("phip_vec_norm", C.c_int, [_vp, C.c_int32, _vp, C.c_int, _pD]),
     ("phip_vec_mdot", C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.POINTER(_vp), _pD]),

@@ -106,6 +106,17 @@ struct phip_mat_s {
   int32_t *d_horder; /* [n] x'[k] = x[horder[k]] */
   double  *d_hx;     /* [n] x in the hot order, refilled by every product */
   double   hot_share[2]; /* share of the gathers that fall into the hottest HOT_LINES lines of x, before / after */
+  /* hot columns resident in LDS (spmv_wave_lds_kernel, setup_lds): the K most used columns get the slots 0..K-1 */
+  int      lds_built, lds_on;
+  int32_t  lds_K;
+  double   lds_share;   /* share of the nonzeros whose column is one of the K */
+  int32_t *d_lcol;      /* [nnz + pad] slot (< K) of a hot column, K + column otherwise; NULL when the hot-column order is built (d_hcol serves: hot columns come first in it) */
+  int32_t *d_hotlist;   /* [K] column of each slot */
+  int32_t *d_wbase;     /* [nwb + 1] rowptr[wblkrow[b]]: first nonzero of each wave block */
+  int32_t *d_wblkrow;   /* [nwb + 1] wave-block plan: block b = stored rows [wblkrow[b], wblkrow[b+1]) , <= WB_CAP nonzeros, <= 64 rows */
+  uint8_t *d_wblktpr;   /* [nwb] log2(lanes per row) of the block's reduce phase */
+  int32_t  nwb;
+  double  *d_wavepart;  /* fused dot: one partial per wave of the grid */
   int      nt_user;  /* phip_mat_set_nontemporal: -1 by size (default), 0 cached loads, 1 non-temporal loads of the matrix stream */
 };
 
@@ -703,6 +714,160 @@ __global__ __launch_bounds__(PHIP_THREADS) void dot_wave_partials_kernel(const d
   reduce_tail<1, 0>(a1, lds, c);
 }
 
+/* ---- hot columns resident in LDS -----------------------------------------------------------------------------------------------------
+   The row-block kernel above runs an irregular matrix at the rate of divergent gathers: every nonzero is one 8-byte load, the 64 lanes
+   of a wave instruction hit 64 different cache lines, and the texture path works them off line by line (about 3 clocks per gather and
+   CU even when every line is an L2 hit: DESIGN.md section 3, R-MAT).  LDS has no lines: a wave's 64 scattered 8-byte reads cost a few
+   clocks.  Power-law matrices spend a large share of their gathers on few columns (R-MAT scale 24: about 30 % on the 16 000 most used
+   of 16.8 M), so those entries of x are copied into LDS once per workgroup and gathered from there; only the rest goes through the
+   texture path.  For LDS to be shared by enough waves the kernel is persistent: ONE 1024-thread workgroup per CU fills its 127 KiB of
+   hot x and then its 16 waves walk the matrix independently of each other -- a WAVE, not a workgroup, owns a block of rows (<= WB_CAP
+   nonzeros, <= 64 rows), streams its values and columns coalesced, stages the products in 2 KiB of LDS of its own and sums each row with
+   1..64 lanes as spmv_reduce_rows does (one lane per row: k-ascending from 0.0 or y[i], the reference's bits).  No workgroup barrier
+   after the fill, so 16 waves hide each other's latency.  Column indices: c < K is an LDS slot, otherwise x_cold[c - coff]. */
+#define WB_CAP 254
+#define WB_STAGE 256
+#define WB_ROWS 64
+#define LDSK_THREADS 1024
+#define LDSK_WAVES (LDSK_THREADS / 64)
+
+/* row sums of one wave block out of the wave's LDS stage.  rpl: lane l holds rowptr[r0 + l] (the block has at most 64 rows; the entry
+   after the last row is `end`), so the row bounds come from a lane exchange instead of memory */
+template <int TPR, bool DOT>
+__device__ __forceinline__ void wave_reduce_rows(const double *prod, int rpl, int end, const int32_t *__restrict__ ridx, const double *__restrict__ yin,
+                                                 double *__restrict__ yout, int r0, int r1, int abase, bool add, bool cprow, const double *__restrict__ dotv,
+                                                 double &dacc, int lane)
+{
+  constexpr int RPP = 64 / TPR; /* rows per pass */
+  const int     nrows = r1 - r0;
+  const int     passes = (nrows + RPP - 1) / RPP;
+  const int     sub = lane % TPR;
+  for (int p = 0; p < passes; p++) {
+    const int  rr = p * RPP + lane / TPR;
+    const bool valid = rr < nrows;
+    const int  s0 = __shfl(rpl, rr & 63, 64), e0 = __shfl(rpl, (rr + 1) & 63, 64);
+    const int  s = valid ? s0 - abase : 0, e = valid ? (rr + 1 == nrows ? end : e0) - abase : 0;
+    const int  r = r0 + rr;
+    double     sum = 0.0;
+    if (TPR == 1) {
+      if (valid) {
+        const int    rout = cprow ? ridx[r] : r;
+        const double y0 = add ? yin[rout] : 0.0;
+        sum = y0;
+        for (int j = s; j < e; j++) sum += prod[j];
+        yout[rout] = sum;
+        if (DOT) dacc += dotv[rout] * (add ? sum - y0 : sum);
+      }
+    } else {
+      for (int j = s + sub; j < e; j += TPR) sum += prod[j];
+#pragma unroll
+      for (int o = TPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      if (valid && sub == 0) {
+        const int rout = cprow ? ridx[r] : r;
+        if (DOT) dacc += dotv[rout] * sum;
+        if (add) sum += yin[rout];
+        yout[rout] = sum;
+      }
+    }
+  }
+}
+
+/* what a wave holds of a block before it works on it: requested one block ahead, so that the stream's latency hides behind the
+   gathers and row sums of the block before */
+struct WaveBlock {
+  int     r0, r1, base, end, tpr, rpl;
+  double2 a[2];
+  int2    c[2];
+};
+
+template <bool NT>
+__device__ __forceinline__ void wave_block_request(WaveBlock &B, int b, const int32_t *__restrict__ wblkrow, const int32_t *__restrict__ wbase, const uint8_t *__restrict__ wblktpr,
+                                                   const int32_t *__restrict__ rowptr, const int32_t *__restrict__ lcol, const double *__restrict__ val, int lane)
+{
+  B.r0 = wblkrow[b]; B.r1 = wblkrow[b + 1]; B.base = wbase[b]; B.end = wbase[b + 1]; B.tpr = wblktpr[b];
+  B.rpl = (lane < B.r1 - B.r0) ? rowptr[B.r0 + lane] : B.end;
+  if (B.end - B.base > WB_CAP) return; /* a long row: streamed when its turn comes */
+  const int abase = B.base & ~1;     /* value pairs are 16-byte aligned */
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int e = abase + 2 * (lane + 64 * k);
+    B.a[k] = make_double2(0.0, 0.0); B.c[k] = make_int2(0, 0);
+    if (e < B.end) {
+      B.a[k] = ld_stream<NT>(reinterpret_cast<const double2 *>(val + e));
+      B.c[k] = ld_stream<NT>(reinterpret_cast<const int2 *>(lcol + e));
+    }
+  }
+}
+
+template <bool DOT, bool NT>
+__global__ __launch_bounds__(LDSK_THREADS) void spmv_wave_lds_kernel(int32_t nwb, const int32_t *__restrict__ wblkrow, const int32_t *__restrict__ wbase,
+                                                                     const uint8_t *__restrict__ wblktpr, const int32_t *__restrict__ rowptr,
+                                                                     const int32_t *__restrict__ ridx, const int32_t *__restrict__ lcol, const double *__restrict__ val,
+                                                                     const double *__restrict__ xhot, const int32_t *__restrict__ hotlist, int K,
+                                                                     const double *__restrict__ xcold, int coff, const double *__restrict__ yin,
+                                                                     double *__restrict__ yout, int add, int cprow, const double *__restrict__ dotv,
+                                                                     double *__restrict__ wavepart)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds_all[]; /* [Kpad] hot x, then LDSK_WAVES stages of WB_STAGE products */
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int Kpad = (K + 1) & ~1;
+  const int gw = (int)blockIdx.x * LDSK_WAVES + w, nw = (int)gridDim.x * LDSK_WAVES;
+  WaveBlock cur, nxt;
+  if (gw < nwb) wave_block_request<NT>(cur, gw, wblkrow, wbase, wblktpr, rowptr, lcol, val, lane); /* in flight while LDS fills */
+  for (int k = t; k < K; k += LDSK_THREADS) lds_all[k] = hotlist ? xhot[hotlist[k]] : xhot[k];
+  __syncthreads();
+  double *prod = lds_all + Kpad + w * WB_STAGE;
+  double  dacc = 0.0;
+  auto    X = [&](int c) -> double { return c < K ? lds_all[c] : xcold[c - coff]; };
+  for (int b = gw; b < nwb; b += nw) {
+    if (b + nw < nwb) wave_block_request<NT>(nxt, b + nw, wblkrow, wbase, wblktpr, rowptr, lcol, val, lane);
+    if (cur.end - cur.base > WB_CAP) { /* one long row (the plan guarantees r1 == r0 + 1): the wave strides over it */
+      double sum = 0.0;
+      for (int j = cur.base + lane; j < cur.end; j += 64) sum += val[j] * X(lcol[j]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      if (lane == 0) {
+        const int rout = cprow ? ridx[cur.r0] : cur.r0;
+        if (DOT) dacc += dotv[rout] * sum;
+        if (add) sum += yin[rout];
+        yout[rout] = sum;
+      }
+    } else {
+      const int abase = cur.base & ~1;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        if (abase + 2 * (lane + 64 * k) < cur.end) {
+          double2 p;
+          p.x = cur.a[k].x * X(cur.c[k].x);
+          p.y = cur.a[k].y * X(cur.c[k].y);
+          *reinterpret_cast<double2 *>(prod + 2 * (lane + 64 * k)) = p;
+        }
+      }
+      /* the wave's own stage: its LDS accesses execute in order, the fences only keep the compiler from moving them */
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      switch (cur.tpr) {
+      case 0: wave_reduce_rows<1, DOT>(prod, cur.rpl, cur.end, ridx, yin, yout, cur.r0, cur.r1, abase, add, cprow, dotv, dacc, lane); break;
+      case 1: wave_reduce_rows<2, DOT>(prod, cur.rpl, cur.end, ridx, yin, yout, cur.r0, cur.r1, abase, add, cprow, dotv, dacc, lane); break;
+      case 2: wave_reduce_rows<4, DOT>(prod, cur.rpl, cur.end, ridx, yin, yout, cur.r0, cur.r1, abase, add, cprow, dotv, dacc, lane); break;
+      case 3: wave_reduce_rows<8, DOT>(prod, cur.rpl, cur.end, ridx, yin, yout, cur.r0, cur.r1, abase, add, cprow, dotv, dacc, lane); break;
+      case 4: wave_reduce_rows<16, DOT>(prod, cur.rpl, cur.end, ridx, yin, yout, cur.r0, cur.r1, abase, add, cprow, dotv, dacc, lane); break;
+      case 5: wave_reduce_rows<32, DOT>(prod, cur.rpl, cur.end, ridx, yin, yout, cur.r0, cur.r1, abase, add, cprow, dotv, dacc, lane); break;
+      default: wave_reduce_rows<64, DOT>(prod, cur.rpl, cur.end, ridx, yin, yout, cur.r0, cur.r1, abase, add, cprow, dotv, dacc, lane); break;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    cur = nxt;
+  }
+  if (DOT) { /* one partial per wave, summed by dot_wave_partials_kernel */
+    dacc = wave_sum(dacc);
+    if (lane == 0) wavepart[gw] = dacc;
+  }
+}
+
 __global__ void getdiag_kernel(int32_t m, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx, int32_t R,
                                const int32_t *__restrict__ col, const double *__restrict__ val, double *__restrict__ v, int cprow)
 {
@@ -751,7 +916,21 @@ static void free_hot(phip_mat A)
   A->d_hcol = NULL; A->d_horder = NULL; A->d_hx = NULL; A->hot_built = 0; A->hot_on = 0;
 }
 
-static int setup_hot(phip_mat A, const int32_t *h_j)
+/* columns by descending use, ties by ascending index (a counting sort over the use counts): order[k] = column in place k, newcol = its inverse */
+static void column_use_order(const int32_t *h_j, int64_t nnz, int32_t n, std::vector<int32_t> &order, std::vector<int32_t> &newcol)
+{
+  std::vector<int32_t> cnt((size_t)n, 0);
+  order.assign((size_t)n, 0); newcol.assign((size_t)n, 0);
+  for (int64_t k = 0; k < nnz; k++) cnt[(size_t)h_j[k]]++;
+  int32_t maxc = 0;
+  for (int32_t c = 0; c < n; c++) maxc = std::max(maxc, cnt[(size_t)c]);
+  std::vector<int64_t> start((size_t)maxc + 2, 0);
+  for (int32_t c = 0; c < n; c++) start[(size_t)(maxc - cnt[(size_t)c]) + 1]++;
+  for (size_t q = 1; q < start.size(); q++) start[q] += start[q - 1];
+  for (int32_t c = 0; c < n; c++) { const int32_t k = (int32_t)start[(size_t)(maxc - cnt[(size_t)c])]++; order[(size_t)k] = c; newcol[(size_t)c] = k; }
+}
+
+static int setup_hot(phip_mat A, const int32_t *h_j, std::vector<int32_t> &order, std::vector<int32_t> &newcol)
 {
   free_hot(A);
   if (g_hot_mode < 0) g_hot_mode = getenv("PHIP_HOT_COLUMNS") ? atoi(getenv("PHIP_HOT_COLUMNS")) : 1;
@@ -759,17 +938,7 @@ static int setup_hot(phip_mat A, const int32_t *h_j)
   if (A->ctx->device < 0 || mode == 0 || A->nnz == 0 || A->n == 0 || A->sell_on) return 0;
   if (mode != 2 && (int64_t)sizeof(double) * A->n < HOT_MIN_BYTES) return 0;
   const int32_t n = A->n;
-  /* columns by descending use, ties by ascending index: a counting sort over the use counts */
-  std::vector<int32_t> cnt((size_t)n, 0), order((size_t)n), newcol((size_t)n);
-  for (int64_t k = 0; k < A->nnz; k++) cnt[(size_t)h_j[k]]++;
-  {
-    int32_t maxc = 0;
-    for (int32_t c = 0; c < n; c++) maxc = std::max(maxc, cnt[(size_t)c]);
-    std::vector<int64_t> start((size_t)maxc + 2, 0);
-    for (int32_t c = 0; c < n; c++) start[(size_t)(maxc - cnt[(size_t)c]) + 1]++;
-    for (size_t q = 1; q < start.size(); q++) start[q] += start[q - 1];
-    for (int32_t c = 0; c < n; c++) { const int32_t k = (int32_t)start[(size_t)(maxc - cnt[(size_t)c])]++; order[(size_t)k] = c; newcol[(size_t)c] = k; }
-  }
+  column_use_order(h_j, A->nnz, n, order, newcol);
   A->hot_share[0] = hot_line_share(h_j, A->nnz, n, NULL);
   A->hot_share[1] = hot_line_share(h_j, A->nnz, n, newcol.data());
   if (mode != 2 && A->hot_share[1] - A->hot_share[0] < HOT_MIN_GAIN) return 0;
@@ -783,6 +952,134 @@ static int setup_hot(phip_mat A, const int32_t *h_j)
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_horder, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipStreamSynchronize(st));
   A->hot_built = 1; A->hot_on = 1;
+  return 0;
+}
+
+/* ---- hot columns in LDS: set-up (spmv_wave_lds_kernel) ---------------------------------------------------------------------------
+   OFF BY DEFAULT (PHIP_LDS_HOT / phip_set_default_lds_hot: 0 never = default, 1 by the rule below, 2 whenever the matrix has nonzeros).
+   Measured on MI355X, R-MAT (profiles/r02_exp_rmat_lds.jsonl): scale 20 (57.6 % of the nonzeros in the K = 16 256 columns LDS holds)
+   391 us against 123 us for the row-block kernel, scale 22 (40.6 %) 1543 against 479 us -- the few rows with tens of thousands of
+   nonzeros are walked by ONE wave each; with every row cut to 254 nonzeros 68.9 against 71.6 us: even then, with two thirds of the
+   gathers out of LDS, the kernel only draws level, because 16 waves a CU (what one 1024-thread workgroup per CU leaves) cannot hide
+   the chain stream -> gather -> stage -> row sums of a 254-nonzero block, requesting the next block's stream one block ahead
+   notwithstanding.  What it would take: two or three blocks of a wave in flight at once and long rows cut into chunks with a
+   deterministic second pass.  Kept, tested and switchable because its results are exact and the analysis is worth having.
+   Rule of mode 1: a row-block (non-stencil) matrix of 2^20 nonzeros or more whose K most used columns carry at least LDS_MIN_SHARE of
+   the nonzeros.  With the hot-column order of setup_hot in place its numbering is used as it is (the hot columns come first);
+   otherwise a column list of its own is built: slot of a hot column, K + column for the others, and x is gathered where it lies. */
+#define LDS_MIN_SHARE 0.10
+#define LDS_MIN_NNZ (1 << 20)
+static int g_lds_mode = -1;
+
+static void free_lds(phip_mat A)
+{
+  if (A->ctx->device >= 0) { hipFree(A->d_lcol); hipFree(A->d_hotlist); hipFree(A->d_wblkrow); hipFree(A->d_wblktpr); hipFree(A->d_wavepart); hipFree(A->d_wbase); }
+  A->d_wbase = NULL; A->d_lcol = NULL; A->d_hotlist = NULL; A->d_wblkrow = NULL; A->d_wblktpr = NULL; A->d_wavepart = NULL;
+  A->lds_built = 0; A->lds_on = 0; A->lds_K = 0; A->nwb = 0; A->lds_share = 0.0;
+}
+
+static uint8_t choose_tpr_log2_wave(int nrows, int maxlen)
+{
+  int best = 0, bestcost = 1 << 30;
+  for (int l = 0; l <= 6; l++) {
+    const int tpr = 1 << l, rpp = 64 / tpr;
+    const int cost = ((nrows + rpp - 1) / rpp) * (((maxlen + tpr - 1) / tpr) + 2) + 2 * l;
+    if (cost < bestcost) { bestcost = cost; best = l; }
+  }
+  return (uint8_t)best;
+}
+
+static void build_plan_wave(const std::vector<int32_t> &rp, int32_t R, int32_t tpr_user, std::vector<int32_t> &blkrow, std::vector<uint8_t> &blktpr)
+{
+  blkrow.clear(); blktpr.clear();
+  blkrow.push_back(0);
+  uint8_t forced = 255;
+  if (tpr_user > 0) { forced = 0; while ((1 << forced) < tpr_user && forced < 6) forced++; }
+  int32_t r = 0;
+  while (r < R) {
+    const int32_t start = r;
+    int32_t       len = rp[(size_t)r + 1] - rp[(size_t)r];
+    int           maxlen = 0;
+    if (len > WB_CAP) { r++; maxlen = len; }
+    else {
+      int64_t nnz = 0;
+      while (r < R && r - start < WB_ROWS) {
+        len = rp[(size_t)r + 1] - rp[(size_t)r];
+        if (nnz + len > WB_CAP) break;
+        nnz += len;
+        if (len > maxlen) maxlen = len;
+        r++;
+      }
+    }
+    blkrow.push_back(r);
+    blktpr.push_back(forced != 255 ? forced : choose_tpr_log2_wave(r - start, maxlen));
+  }
+}
+
+template <bool DOT, bool NT>
+static int lds_kernel_allow(size_t bytes)
+{
+  PHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_wave_lds_kernel<DOT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return 0;
+}
+
+static int upload_plan_wave(phip_mat A)
+{
+  std::vector<int32_t> wblkrow;
+  std::vector<uint8_t> wblktpr;
+  build_plan_wave(*A->h_rowptr, A->R, A->tpr_user, wblkrow, wblktpr);
+  A->nwb = (int32_t)wblktpr.size();
+  hipStream_t st = A->ctx->stream;
+  if (A->d_wblkrow) { hipFree(A->d_wblkrow); A->d_wblkrow = NULL; }
+  if (A->d_wblktpr) { hipFree(A->d_wblktpr); A->d_wblktpr = NULL; }
+  if (A->d_wbase) { hipFree(A->d_wbase); A->d_wbase = NULL; }
+  std::vector<int32_t> wbase(wblkrow.size());
+  for (size_t b = 0; b < wblkrow.size(); b++) wbase[b] = (*A->h_rowptr)[(size_t)wblkrow[b]];
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_wbase, sizeof(int32_t) * wbase.size()));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_wbase, wbase.data(), sizeof(int32_t) * wbase.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_wblkrow, sizeof(int32_t) * wblkrow.size()));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_wblktpr, wblktpr.size() + 16));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_wblkrow, wblkrow.data(), sizeof(int32_t) * wblkrow.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_wblktpr, wblktpr.data(), wblktpr.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+static int setup_lds(phip_mat A, const int32_t *h_j, std::vector<int32_t> &order, std::vector<int32_t> &newcol)
+{
+  free_lds(A);
+  if (g_lds_mode < 0) g_lds_mode = getenv("PHIP_LDS_HOT") ? atoi(getenv("PHIP_LDS_HOT")) : 0; /* off by default: measured, see above */
+  const int mode = g_lds_mode;
+  if (A->ctx->device < 0 || mode == 0 || A->nnz == 0 || A->n == 0 || A->sell_on) return 0;
+  if (mode != 2 && A->nnz < LDS_MIN_NNZ) return 0;
+  int maxlds = 0;
+  PHIP_CHECK_HIP(hipDeviceGetAttribute(&maxlds, hipDeviceAttributeMaxSharedMemoryPerBlock, A->ctx->device));
+  const int64_t room = ((int64_t)maxlds - (int64_t)sizeof(double) * LDSK_WAVES * WB_STAGE - 1024) / (int64_t)sizeof(double);
+  if (room < 1024) return 0;
+  int32_t K = (int32_t)std::min<int64_t>(room & ~127ll, A->n);
+  if (order.empty()) column_use_order(h_j, A->nnz, A->n, order, newcol);
+  int64_t hot = 0;
+  for (int64_t k = 0; k < A->nnz; k++) hot += newcol[(size_t)h_j[k]] < K;
+  A->lds_share = (double)hot / (double)A->nnz;
+  if (mode != 2 && A->lds_share < LDS_MIN_SHARE) return 0;
+  A->lds_K = K;
+  hipStream_t st = A->ctx->stream;
+  if (!A->hot_built) { /* a column list of its own: slot of a hot column, K + column otherwise; x stays where it is */
+    std::vector<int32_t> lcol((size_t)A->nnz + 8, 0);
+    for (int64_t k = 0; k < A->nnz; k++) { const int32_t c = h_j[k], q = newcol[(size_t)c]; lcol[(size_t)k] = q < K ? q : K + c; }
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_lcol, sizeof(int32_t) * lcol.size()));
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_hotlist, sizeof(int32_t) * ((size_t)K + 4)));
+    PHIP_CHECK_HIP(hipMemcpyAsync(A->d_lcol, lcol.data(), sizeof(int32_t) * lcol.size(), hipMemcpyHostToDevice, st));
+    PHIP_CHECK_HIP(hipMemcpyAsync(A->d_hotlist, order.data(), sizeof(int32_t) * (size_t)K, hipMemcpyHostToDevice, st));
+    PHIP_CHECK_HIP(hipStreamSynchronize(st));
+  }
+  int rc = upload_plan_wave(A);
+  if (rc) return rc;
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_wavepart, sizeof(double) * ((size_t)A->ctx->cu_count * LDSK_WAVES + 16)));
+  const size_t bytes = sizeof(double) * ((size_t)((K + 1) & ~1) + (size_t)LDSK_WAVES * WB_STAGE);
+  if ((rc = lds_kernel_allow<false, false>(bytes)) || (rc = lds_kernel_allow<false, true>(bytes)) || (rc = lds_kernel_allow<true, false>(bytes)) ||
+      (rc = lds_kernel_allow<true, true>(bytes))) return rc;
+  A->lds_built = 1; A->lds_on = 1;
   return 0;
 }
 
@@ -1219,7 +1516,11 @@ extern "C" int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t
   int rc = upload_plan(A);
   if (rc) return rc;
   if ((rc = setup_sell(A, h_j, h_a))) return rc;
-  if ((rc = setup_hot(A, h_j))) return rc;
+  {
+    std::vector<int32_t> order, newcol;
+    if ((rc = setup_hot(A, h_j, order, newcol))) return rc;
+    if ((rc = setup_lds(A, h_j, order, newcol))) return rc;
+  }
   *out = A;
   return 0;
 }
@@ -1257,6 +1558,7 @@ extern "C" int phip_mat_destroy(phip_mat A)
   hipStreamSynchronize(A->ctx->stream);
   free_sell(A);
   free_hot(A);
+  free_lds(A);
   delete A->h_sptr;
   hipFree(A->d_rowptr); hipFree(A->d_ridx); hipFree(A->d_col); hipFree(A->d_val); hipFree(A->d_blkrow); hipFree(A->d_blktpr);
   delete A->h_rowptr; delete A->h_blkrow; delete A->h_blktpr;
@@ -1370,6 +1672,26 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     const bool       csr_nt = A->nt_user >= 0 ? A->nt_user != 0 : (csr_nt_env >= 0 ? csr_nt_env != 0 : (12 * A->nnz > PHIP_NT_MATRIX_BYTES && !A->use_cprow));
     const int32_t   *cols = A->d_col;
     const double    *xs = d_x;
+    const bool       hot = A->hot_built && A->hot_on;
+    if (A->lds_built && A->lds_on && A->nwb && (hot || A->d_lcol)) { /* hot columns from LDS, one wave per block of rows (spmv_wave_lds_kernel) */
+      if (hot) {
+        const unsigned g = (unsigned)std::min<int64_t>(((int64_t)A->n + 1023) / 1024, 16384);
+        hipLaunchKernelGGL(hot_gather_kernel, dim3(g), dim3(256), 0, st, A->n, A->d_horder, d_x, A->d_hx);
+      }
+      const int32_t K = A->lds_K;
+      const size_t  bytes = sizeof(double) * ((size_t)((K + 1) & ~1) + (size_t)LDSK_WAVES * WB_STAGE);
+      const unsigned lgrid = (unsigned)std::min<int64_t>(A->ctx->cu_count, ((int64_t)A->nwb + LDSK_WAVES - 1) / LDSK_WAVES);
+#define LDS_LAUNCH(NTv)                                                                                                                                   \
+  hipLaunchKernelGGL((spmv_wave_lds_kernel<DOT, NTv>), dim3(lgrid), dim3(LDSK_THREADS), bytes, st, A->nwb, A->d_wblkrow, A->d_wbase, A->d_wblktpr, A->d_rowptr, A->d_ridx,  \
+                     hot ? A->d_hcol : A->d_lcol, A->d_val, hot ? A->d_hx : d_x, hot ? (const int32_t *)NULL : A->d_hotlist, K, hot ? A->d_hx : d_x,       \
+                     hot ? 0 : K, d_yin, d_yout, add, A->use_cprow, d_v, A->d_wavepart)
+      if (csr_nt) LDS_LAUNCH(true); else LDS_LAUNCH(false);
+#undef LDS_LAUNCH
+      if (DOT) hipLaunchKernelGGL(dot_wave_partials_kernel, dim3(phip_grid_for((int64_t)lgrid * LDSK_WAVES, 16, PHIP_RED_GRID)), dim3(PHIP_THREADS), 0, st, A->d_wavepart,
+                                  (int)(lgrid * LDSK_WAVES), ctl);
+      PHIP_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
     if (A->hot_on && A->nblocks) { /* x in the hot-column order (setup_hot) */
       const unsigned g = (unsigned)std::min<int64_t>(((int64_t)A->n + 1023) / 1024, 16384);
       hipLaunchKernelGGL(hot_gather_kernel, dim3(g), dim3(256), 0, st, A->n, A->d_horder, d_x, A->d_hx);
@@ -1564,6 +1886,7 @@ extern "C" int phip_mat_set_threads_per_row(phip_mat A, int32_t tpr)
   PHIP_REQUIRE(tpr >= 0 && tpr <= 64 && (tpr & (tpr - 1)) == 0, PHIP_ERR_ARG_OUTOFRANGE, "threads per row must be 0 or a power of two <= 64, got %d", tpr);
   A->tpr_user = tpr;
   if (A->T) { int rc = phip_mat_set_threads_per_row(A->T, tpr); if (rc) return rc; }
+  if (A->lds_built) { int rc = upload_plan_wave(A); if (rc) return rc; }
   return upload_plan(A);
 }
 
@@ -1611,6 +1934,33 @@ extern "C" int phip_mat_hot_columns_info(phip_mat A, int *built, int *in_use, do
   if (in_use) *in_use = A->hot_on && !A->sell_on;
   if (share_before) *share_before = A->hot_share[0];
   if (share_after) *share_after = A->hot_share[1];
+  return 0;
+}
+
+/* hot columns resident in LDS (setup_lds): on = 0 runs the row-block kernel, 1 the wave kernel built at creation (error if none was
+   built).  info: built / in use / K / share of the nonzeros whose column is one of the K. */
+extern "C" int phip_set_default_lds_hot(int mode)
+{
+  PHIP_REQUIRE(mode >= 0 && mode <= 2, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_default_lds_hot: %d (0 never, 1 when it pays, 2 always)", mode);
+  g_lds_mode = mode;
+  return 0;
+}
+
+extern "C" int phip_mat_set_lds_hot(phip_mat A, int on)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_set_lds_hot: null matrix");
+  PHIP_REQUIRE(!on || A->lds_built, PHIP_ERR_SUP, "phip_mat_set_lds_hot: no LDS plan was built for this matrix");
+  A->lds_on = on ? 1 : 0;
+  return 0;
+}
+
+extern "C" int phip_mat_lds_hot_info(phip_mat A, int *built, int *in_use, int32_t *K, double *share)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_lds_hot_info: null matrix");
+  if (built) *built = A->lds_built;
+  if (in_use) *in_use = A->lds_built && A->lds_on && !A->sell_on && ((A->hot_built && A->hot_on) || A->d_lcol);
+  if (K) *K = A->lds_K;
+  if (share) *share = A->lds_share;
   return 0;
 }
 

@@ -494,6 +494,7 @@ def test_hot_column_order(ctx, orc):
             out = {}
             for on in (1, 0):
                 ctx.check(L.phip_mat_set_hot_columns(A, on))
+                ctx.check(L.phip_mat_set_lds_hot(A, 0))        # the row-block kernel; the wave kernel has a test of its own below
                 ctx.check(L.phip_mat_mult(A, dx, dy))
                 ctx.check(L.phip_mat_multadd(A, dx, dy0, dz))
                 t = Ticket()
@@ -517,6 +518,121 @@ def test_hot_column_order(ctx, orc):
         assert info(A)[:2] == (0, 0)
         ctx.check(L.phip_mat_destroy(A))
     finally:
+        ctx.check(L.phip_set_default_hot_columns(1))
+
+
+def test_lds_hot_columns_wave_kernel(ctx, orc):
+    """spmv_wave_lds_kernel (the K most used columns of x resident in LDS, one wave per block of rows): mult, multadd (also in place), the
+    fused dot and the compressed-row form against the oracle (<= 1e-12; bit for bit with one lane per row) and against the row-block
+    kernel; with and without the hot-column order underneath; built by the default rule for an R-MAT of 2^20 nonzeros and more, never for
+    stencil or small matrices; K and the share of nonzeros served from LDS are reported."""
+    import ctypes as C
+    from petsc_amd import generators as G
+    from petsc_amd.capi import Ticket
+    L = ctx.lib
+    rng = np.random.default_rng(78)
+
+    def info(A):
+        b, u, K, sh = C.c_int(), C.c_int(), C.c_int32(), C.c_double()
+        ctx.check(L.phip_mat_lds_hot_info(A, C.byref(b), C.byref(u), C.byref(K), C.byref(sh)))
+        return b.value, u.value, K.value, sh.value
+
+    # off by default; by its rule (mode 1) R-MAT scale 17 (2.0 M nonzeros) gets the plan, scale 13 and a stencil do not
+    ai, aj, aa = G.rmat(17)
+    n = len(ai) - 1
+    A = ctx.mat_create(n, n, ai, aj, aa)
+    assert info(A)[:2] == (0, 0)
+    ctx.check(L.phip_mat_destroy(A))
+    ctx.check(L.phip_set_default_lds_hot(1))
+    A = ctx.mat_create(n, n, ai, aj, aa)
+    built, used, K, share = info(A)
+    assert (built, used) == (1, 1) and 1024 <= K <= 20000 and share >= 0.10, (built, used, K, share)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(n)
+    dx, dy, dy0 = ctx.to_device(x), ctx.to_device(np.zeros(n)), ctx.to_device(y0)
+    res = {}
+    for on in (1, 0):
+        ctx.check(L.phip_mat_set_lds_hot(A, on))
+        ctx.check(L.phip_mat_mult(A, dx, dy))
+        res[on] = ctx.to_host(dy, n)
+    yo = orc.matmult(ai, aj, aa, x)
+    assert relerr(res[1], yo) <= 1e-12 and relerr(res[0], yo) <= 1e-12
+    ctx.check(L.phip_mat_set_lds_hot(A, 1))
+    ctx.check(L.phip_mat_set_threads_per_row(A, 1))     # one lane per row: the oracle's bits
+    ctx.check(L.phip_mat_mult(A, dx, dy))
+    short = np.diff(ai) <= 254                           # a row longer than a wave block is summed by the whole wave (strided + tree)
+    assert 0 < np.count_nonzero(~short) < n // 50
+    y1 = ctx.to_host(dy, n)
+    np.testing.assert_array_equal(y1[short], yo[short])
+    assert relerr(y1, yo) <= 1e-12
+    ctx.check(L.phip_mat_multadd(A, dx, dy0, dy0))      # in place, as MatMult_MPIAIJ calls it
+    z1, zo = ctx.to_host(dy0, n), orc.matmultadd(ai, aj, aa, x, y0)
+    np.testing.assert_array_equal(z1[short], zo[short])
+    assert relerr(z1, zo) <= 1e-12
+    for pz in (dx, dy, dy0):
+        ctx.free(pz)
+    ctx.check(L.phip_mat_destroy(A))
+    for gi, gj, ga in (G.rmat(13), G.laplace3d_7pt(40)):
+        A = ctx.mat_create(len(gi) - 1, len(gi) - 1, gi, gj, ga)
+        assert info(A)[:2] == (0, 0)
+        assert L.phip_mat_set_lds_hot(A, 1) != 0
+        ctx.check(L.phip_mat_destroy(A))
+    # forced on small matrices of every shape: compressed rows, a row longer than a wave block, rectangular; with the hot order under it and without
+    ctx.check(L.phip_set_default_lds_hot(2))
+    try:
+        nz_rows = np.sort(rng.choice(500, 60, replace=False)).astype(np.int32)
+        ri = np.zeros(501, dtype=np.int32)
+        ri[nz_rows + 1] = rng.integers(1, 40, 60)
+        ri = np.cumsum(ri).astype(np.int32)
+        rj = np.concatenate([np.sort(rng.choice(3000, ri[r + 1] - ri[r], replace=False)) for r in range(500)]).astype(np.int32)
+        ra = rng.standard_normal(len(rj))
+        cp = (np.concatenate([[0], np.cumsum(np.diff(ri)[nz_rows])]).astype(np.int32), nz_rows)
+        li = np.array([0, 3, 5003, 5004, 5004, 5260], dtype=np.int32)
+        lj = np.concatenate([[0, 2, 5], np.arange(5000), [7], np.arange(0, 5120, 20)]).astype(np.int32)
+        la = rng.standard_normal(len(lj))
+        si, sj, sa = G.rmat(12)
+        wide = 40000                                      # more columns than LDS holds: hot and cold gathers in one product
+        wi = np.arange(0, 301 * 50, 50).astype(np.int32)
+        wj = np.concatenate([np.sort(rng.choice(wide, 50, replace=False)) for _ in range(300)]).astype(np.int32)
+        wj[::3] = wj[::3] % 100                           # a few very hot columns (duplicates within a row are fine for the kernels)
+        wj = np.concatenate([np.sort(wj[k * 50:(k + 1) * 50]) for k in range(300)]).astype(np.int32)
+        wa = rng.standard_normal(len(wj))
+        cases = [(si, sj, sa, len(si) - 1, None), (ri, rj, ra, 3000, cp), (li, lj, la, 5200, None), (wi, wj, wa, wide, None)]
+        for hotmode in (1, 2):
+            ctx.check(L.phip_set_default_hot_columns(hotmode))
+            for ci, cj, ca, ncols, cprow in cases:
+                m = len(ci) - 1
+                x, v, y0 = rng.standard_normal(ncols), rng.standard_normal(m), rng.standard_normal(m)
+                A = ctx.mat_create(m, ncols, ci, cj, ca, cprow)
+                built, used, K, share = info(A)
+                assert (built, used) == (1, 1) and K == min(ncols, K) and 0.0 < share <= 1.0
+                dx, dv, dy0 = ctx.to_device(x), ctx.to_device(v), ctx.to_device(y0)
+                dy, dz, dt = (ctx.to_device(np.full(m, 3.5)) for _ in range(3))
+                out = {}
+                for on in (1, 0):
+                    ctx.check(L.phip_mat_set_lds_hot(A, on))
+                    for tpr in (0, 1):
+                        ctx.check(L.phip_mat_set_threads_per_row(A, tpr))
+                        ctx.check(L.phip_mat_mult(A, dx, dy))
+                        ctx.check(L.phip_mat_multadd(A, dx, dy0, dz))
+                        t = Ticket()
+                        val = np.zeros(1)
+                        ctx.check(L.phip_mat_mult_dot(A, dx, dt, dv, 1, C.byref(t)))
+                        ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t), val.ctypes.data_as(C.POINTER(C.c_double))))
+                        out[on, tpr] = (ctx.to_host(dy, m), ctx.to_host(dz, m), ctx.to_host(dt, m), val.copy())
+                yo, zo = orc.matmult(ci, cj, ca, x), orc.matmultadd(ci, cj, ca, x, y0)
+                for key, (y, z, yd, val) in out.items():
+                    assert relerr(y, yo) <= 1e-12 and relerr(z, zo) <= 1e-12, key
+                    np.testing.assert_array_equal(yd, y)
+                    assert abs(val[0] - v @ y) <= 1e-12 * np.abs(v * y).sum() + 1e-300, key
+                short = np.diff(ci) <= 254
+                for on in (1, 0):                           # one lane per row: the oracle's bits, whichever kernel
+                    np.testing.assert_array_equal(out[on, 1][0][short], yo[short])
+                    np.testing.assert_array_equal(out[on, 1][1][short], zo[short])
+                for pz in (dx, dv, dy0, dy, dz, dt):
+                    ctx.free(pz)
+                ctx.check(L.phip_mat_destroy(A))
+    finally:
+        ctx.check(L.phip_set_default_lds_hot(0))
         ctx.check(L.phip_set_default_hot_columns(1))
 
 
