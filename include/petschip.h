@@ -97,6 +97,20 @@ int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t *h_i, cons
                     phip_mat *A);
 /* same pattern, new values (MatAssemblyEnd with unchanged nonzerostate; aijcusp.cu:451-462 re-uploads everything) */
 int phip_mat_update_values(phip_mat A, const double *h_a);
+/* Value updates that keep the nonzero pattern, on the device (no value crosses PCIe): the CSR values, the SELL-dict copy, the pair
+ * dictionary / diagonal masks (scaled or shifted exactly as the entries they stand for; dropped by a diagonal scaling, whose values
+ * depend on the position) and the transposed copy.  phip_mat_get_values brings the current values back to a host CSR of the same
+ * pattern when the host needs them again (MatGetRow, MatView, further MatSetValues ...).
+ *   phip_mat_scale            a *= alpha                       MatScale_SeqAIJ, aij.c:2475-2488
+ *   phip_mat_shift            a(i,i) += alpha                  MatShift (axpy.c:154) -> MatShift_Basic (gcreate.c:6-24); rows without a stored
+ *                                                              diagonal entry are left alone: the caller checks (a missing entry changes the pattern)
+ *   phip_mat_diagonal_scale   a(i,j) = (a(i,j) l_i) r_j        MatDiagonalScale_SeqAIJ, aij.c:2200-2235; d_l (m entries) or d_r (n entries) may be NULL
+ *   phip_mat_zero_entries     a = 0                            MatZeroEntries_SeqAIJ, aij.c:1058-1067 */
+int phip_mat_scale(phip_mat A, double alpha);
+int phip_mat_shift(phip_mat A, double alpha);
+int phip_mat_diagonal_scale(phip_mat A, const double *d_l, const double *d_r);
+int phip_mat_zero_entries(phip_mat A);
+int phip_mat_get_values(phip_mat A, double *h_a);
 int phip_mat_destroy(phip_mat A);
 /* y = A x.  MatMult_SeqAIJ, aij.c:1272-1327 (cprow branch :1295-1308 zero-fills y). d_x has n entries, d_y m. */
 int phip_mat_mult(phip_mat A, const double *d_x, double *d_y);

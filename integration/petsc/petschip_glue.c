@@ -500,9 +500,13 @@ PETSC_EXTERN PetscErrorCode VecCreate_HIP(Vec V)            /* mpicusp.cu:237-25
 /* ---- Mat ----------------------------------------------------------------------------------------------------- */
 typedef PetscErrorCode (*MatAssemblyEndFn)(Mat,MatAssemblyType);
 typedef PetscErrorCode (*MatDestroyFn)(Mat);
+typedef PetscErrorCode (*MatScaleFn)(Mat,PetscScalar);
+typedef PetscErrorCode (*MatDiagonalScaleFn)(Mat,Vec,Vec);
+typedef PetscErrorCode (*MatZeroEntriesFn)(Mat);
 typedef enum {MAT_HIP_AUTO=0,MAT_HIP_CSR=1,MAT_HIP_SELL=2} MatHIPStorageFormat;   /* phip_mat_set_format; precedent MatCUSPStorageFormat, petscmat.h */
 static const char *const MatHIPStorageFormats[] = {"AUTO","CSR","SELL","MatHIPStorageFormat","MAT_HIP_",0};
 typedef struct { phip_mat dev,tdev; PetscObjectState state,nonzerostate; MatAssemblyEndFn base_assemblyend; MatDestroyFn base_destroy;
+                 MatScaleFn base_scale; MatDiagonalScaleFn base_diagonalscale; MatZeroEntriesFn base_zeroentries;
                  MatHIPStorageFormat format; PetscBool valuedict,diagmask,hotcolumns,optset; } Mat_SeqAIJHIP; /* B->spptr of the Seq type */
 typedef struct { phip_halo halo; PetscObjectState nonzerostate; MatAssemblyEndFn base_assemblyend; MatDestroyFn base_destroy; } Mat_MPIAIJHIP;      /* Mat_MPIAIJ.spptr (mpiaij.h:77) */
 
@@ -623,6 +627,50 @@ static PetscErrorCode MatGetDiagonal_SeqAIJHIP(Mat A,Vec v)  /* aij.c:1169-1202 
   VEC_DONE(v,pv);
   PetscFunctionReturn(0);
 }
+/* Value updates that keep the nonzero pattern (include/petschip.h): the inherited SeqAIJ routine updates the host CSR, the master copy
+   (every inherited op reads a->a directly), and the SAME update runs on the device copy, so that no value crosses PCIe: the state the
+   interface wrapper is about to set (it increases the object state once after the op, matrix.c:4850,4903,5327) is recorded as already
+   uploaded.  A device copy that is not current is left alone: the next product re-sends the values as before. */
+static PetscBool MatHIPDeviceCurrent(Mat A)
+{
+  Mat_SeqAIJHIP *h = (Mat_SeqAIJHIP*)A->spptr; PetscObjectState st;
+  if (PetscObjectStateGet((PetscObject)A,&st)) return PETSC_FALSE;
+  return (PetscBool)(h->dev && h->nonzerostate == A->nonzerostate && h->state == st);
+}
+static PetscErrorCode MatScale_SeqAIJHIP(Mat A,PetscScalar alpha)            /* aij.c:2475-2488 */
+{
+  Mat_SeqAIJHIP *h = (Mat_SeqAIJHIP*)A->spptr; PetscErrorCode ierr; PetscBool cur = MatHIPDeviceCurrent(A);
+  PetscFunctionBegin;
+  ierr = (*h->base_scale)(A,alpha);CHKERRQ(ierr);
+  if (cur) { CHKERRPHIP(phip_mat_scale(h->dev,alpha)); h->state++; }
+  PetscFunctionReturn(0);
+}
+static PetscErrorCode MatDiagonalScale_SeqAIJHIP(Mat A,Vec ll,Vec rr)        /* aij.c:2200-2235 */
+{
+  Mat_SeqAIJHIP *h = (Mat_SeqAIJHIP*)A->spptr; PetscErrorCode ierr; PetscBool cur = MatHIPDeviceCurrent(A),lhip = PETSC_FALSE,rhip = PETSC_FALSE;
+  const PetscScalar *l = NULL,*r = NULL;
+  PetscFunctionBegin;
+  ierr = (*h->base_diagonalscale)(A,ll,rr);CHKERRQ(ierr);
+  if (ll) { ierr = PetscObjectTypeCompareAny((PetscObject)ll,&lhip,VECSEQHIP,VECMPIHIP,"");CHKERRQ(ierr); }
+  if (rr) { ierr = PetscObjectTypeCompareAny((PetscObject)rr,&rhip,VECSEQHIP,VECMPIHIP,"");CHKERRQ(ierr); }
+  if (cur && (!ll || lhip) && (!rr || rhip)) {                   /* both vectors live on the device: scale the device copy where it is */
+    if (ll) { VEC_R(ll,l); }
+    if (rr) { VEC_R(rr,r); }
+    CHKERRPHIP(phip_mat_diagonal_scale(h->dev,l,r));
+    h->state++;
+  }
+  PetscFunctionReturn(0);
+}
+static PetscErrorCode MatZeroEntries_SeqAIJHIP(Mat A)                        /* aij.c:1058-1067 */
+{
+  Mat_SeqAIJHIP *h = (Mat_SeqAIJHIP*)A->spptr; PetscErrorCode ierr; PetscBool cur = MatHIPDeviceCurrent(A);
+  PetscFunctionBegin;
+  ierr = (*h->base_zeroentries)(A);CHKERRQ(ierr);
+  if (cur) { CHKERRPHIP(phip_mat_zero_entries(h->dev)); h->state++; }
+  PetscFunctionReturn(0);
+}
+/* MatShift: MatShift_Basic (gcreate.c:6-24) goes through MatSetValues + assembly, after which MatHIPCopyToGPU re-sends the values; the
+   device-side form (phip_mat_shift) is bound by the stand-alone mirror (petsc_host.cpp: MatShift_AIJHIP), which owns its assembly state. */
 static PetscErrorCode MatAssemblyEnd_SeqAIJHIP(Mat A,MatAssemblyType mode)   /* aijcusp.cu:451-462 */
 {
   PetscErrorCode ierr;
@@ -669,14 +717,16 @@ PETSC_EXTERN PetscErrorCode MatCreate_SeqAIJHIP(Mat B)
   ierr = PetscNewLog(B,&h);CHKERRQ(ierr);
   B->spptr = h;
   h->base_assemblyend = B->ops->assemblyend; h->base_destroy = B->ops->destroy;
+  h->base_scale = B->ops->scale; h->base_diagonalscale = B->ops->diagonalscale; h->base_zeroentries = B->ops->zeroentries;
+  B->ops->scale = MatScale_SeqAIJHIP; B->ops->diagonalscale = MatDiagonalScale_SeqAIJHIP; B->ops->zeroentries = MatZeroEntries_SeqAIJHIP;
   h->format = MAT_HIP_AUTO; h->valuedict = h->diagmask = h->hotcolumns = PETSC_TRUE; h->optset = PETSC_FALSE;
   B->ops->setfromoptions = MatSetFromOptions_SeqAIJHIP;
   B->ops->mult = MatMult_SeqAIJHIP;               B->ops->multadd = MatMultAdd_SeqAIJHIP;
   B->ops->getdiagonal = MatGetDiagonal_SeqAIJHIP; B->ops->assemblyend = MatAssemblyEnd_SeqAIJHIP;
   B->ops->destroy = MatDestroy_SeqAIJHIP;         B->ops->getvecs = MatCreateVecs_AIJHIP;
   B->ops->multtranspose = MatMultTranspose_SeqAIJHIP; B->ops->multtransposeadd = MatMultTransposeAdd_SeqAIJHIP;
-  /* scale, diagonalscale, shift, zeroentries, setvalues ... stay the SeqAIJ host routines: they bump the object state, and
-     MatHIPCopyToGPU re-sends the values (only) before the next product */
+  /* shift, setvalues ... stay the SeqAIJ host routines: they bump the object state, and MatHIPCopyToGPU re-sends the values (only)
+     before the next product; scale / diagonalscale / zeroentries run on both copies (above) */
   ierr = PetscObjectChangeTypeName((PetscObject)B,MATSEQAIJHIP);CHKERRQ(ierr);
   PetscFunctionReturn(0);
 }

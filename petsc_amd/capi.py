@@ -34,6 +34,11 @@ SIGNATURES = [
     ("phip_profile_durations", C.c_int, [_vp, C.c_int, C.c_int32, C.POINTER(C.c_float), _pI]),
     ("phip_mat_create", C.c_int, [_vp, C.c_int32, C.c_int32, _pI, _pI, _pD, C.c_int, C.c_int32, _pI, _pI, C.POINTER(_vp)]),
     ("phip_mat_update_values", C.c_int, [_vp, _pD]),
+    ("phip_mat_scale", C.c_int, [_vp, C.c_double]),
+    ("phip_mat_shift", C.c_int, [_vp, C.c_double]),
+    ("phip_mat_diagonal_scale", C.c_int, [_vp, _vp, _vp]),
+    ("phip_mat_zero_entries", C.c_int, [_vp]),
+    ("phip_mat_get_values", C.c_int, [_vp, _pD]),
     ("phip_mat_destroy", C.c_int, [_vp]),
     ("phip_mat_mult", C.c_int, [_vp, _vp, _vp]),
     ("phip_mat_multadd", C.c_int, [_vp, _vp, _vp, _vp]),

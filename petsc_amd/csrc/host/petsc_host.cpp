@@ -1071,6 +1071,14 @@ struct HostAIJ {
   bool     cprow_use = false;
   phip_mat dev = NULL;
   bool     t_ready = false;        /* the device matrix carries its transposed copy (phip_mat_transpose_setup) */
+  bool     host_stale = false;     /* MatScale / MatShift / MatDiagonalScale ran on the device: a[] is behind until sync_host() */
+  /* bring a[] up to date before the host reads or changes values (the role of MatCUSPCopyFromGPU-style coherence flags, petscimpl.h:749) */
+  PetscErrorCode sync_host()
+  {
+    if (host_stale && dev) CHKPHIP(phip_mat_get_values(dev, a.data()));
+    host_stale = false;
+    return 0;
+  }
 
   void prealloc(PetscInt m_, PetscInt n_, PetscInt nzrow, const PetscInt *nnz)
   {
@@ -1188,6 +1196,8 @@ struct HostAIJ {
   }
   PetscErrorCode upload(phip_ctx ctx)
   {
+    if (host_stale && !values_dirty && dev && dev_nonzerostate == nonzerostate) return 0; /* the device holds the newer values */
+    { PetscErrorCode ierr = sync_host(); CHKERRQ(ierr); }
     if (dev && dev_nonzerostate == nonzerostate) {
       if (values_dirty) CHKPHIP(phip_mat_update_values(dev, a.data()));
     } else {
@@ -1204,6 +1214,7 @@ struct HostAIJ {
   PetscErrorCode need_transpose()
   {
     if (t_ready) return 0;
+    { PetscErrorCode ierr = sync_host(); CHKERRQ(ierr); }
     CHKPHIP(phip_mat_transpose_setup(dev, ai.data(), j.data(), a.data()));
     t_ready = true;
     return 0;
@@ -1248,6 +1259,13 @@ struct _p_Mat {
   std::vector<StashEntry> stash; int stash_mode;
   bool        mpi;
 };
+
+/* the host CSR values of both blocks, current (after device-side MatScale / MatShift / MatDiagonalScale) */
+static PetscErrorCode mat_sync_host(Mat A)
+{
+  PetscErrorCode ierr = A->A.sync_host(); CHKERRQ(ierr);
+  return A->B.sync_host();
+}
 
 static std::map<std::string, PetscErrorCode (*)(Mat)> &MatList()
 {
@@ -1343,10 +1361,15 @@ static PetscErrorCode MatMultTransposeAdd_SeqAIJHIP(Mat A, Vec x, Vec y, Vec z)
   return 0;
 }
 static PetscErrorCode MatGetDiagonal_SeqAIJHIP(Mat A, Vec v) { CHKPHIP(phip_mat_getdiagonal(A->A.dev, v->d)); return 0; }
-static PetscErrorCode MatZeroEntries_AIJHIP(Mat A)
+static PetscErrorCode MatZeroEntries_AIJHIP(Mat A) /* MatZeroEntries_SeqAIJ aij.c:1058-1067, on both copies: no value travels */
 {
-  std::fill(A->A.a.begin(), A->A.a.end(), 0.0); A->A.values_dirty = true;
-  std::fill(A->B.a.begin(), A->B.a.end(), 0.0); A->B.values_dirty = true;
+  HostAIJ *blk[2] = {&A->A, &A->B};
+  for (int w = 0; w < (A->mpi ? 2 : 1); w++) {
+    std::fill(blk[w]->a.begin(), blk[w]->a.end(), 0.0);
+    blk[w]->host_stale = false;
+    if (blk[w]->dev && blk[w]->assembled && blk[w]->dev_nonzerostate == blk[w]->nonzerostate && !blk[w]->values_dirty) CHKPHIP(phip_mat_zero_entries(blk[w]->dev));
+    else blk[w]->values_dirty = true;
+  }
   return 0;
 }
 /* ---- value updates that keep the nonzero pattern: the host CSR is the master copy (as under the reference's GPU types, whose
@@ -1369,18 +1392,29 @@ static PetscErrorCode mat_upload_values(Mat A)
   if (A->mpi) { ierr = A->B.upload(MCTX(A)); CHKERRQ(ierr); }
   return 0;
 }
-static PetscErrorCode MatScale_AIJHIP(Mat A, PetscScalar a) /* aij.c:2475 / MatScale_MPIAIJ mpiaij.c:1139-1148: both blocks */
+/* is the device copy of the block current, so that a value update can run there? */
+static bool blk_on_device(const HostAIJ &B) { return B.dev && B.assembled && B.dev_nonzerostate == B.nonzerostate && !B.values_dirty; }
+
+static PetscErrorCode MatScale_AIJHIP(Mat A, PetscScalar a) /* aij.c:2475 / MatScale_MPIAIJ mpiaij.c:1139-1148: both blocks, on the device */
 {
-  aij_scale(A->A, a);
-  if (A->mpi) aij_scale(A->B, a);
+  HostAIJ *blk[2] = {&A->A, &A->B};
+  for (int w = 0; w < (A->mpi ? 2 : 1); w++) {
+    if (blk_on_device(*blk[w])) { CHKPHIP(phip_mat_scale(blk[w]->dev, a)); blk[w]->host_stale = true; }
+    else { PetscErrorCode ierr = blk[w]->sync_host(); CHKERRQ(ierr); aij_scale(*blk[w], a); }
+  }
   return mat_upload_values(A);
 }
 static PetscErrorCode MatDiagonalScale_SeqAIJHIP(Mat A, Vec ll, Vec rr)
 {
   if (ll && ll->n != A->m) SETERRQ(PETSC_ERR_ARG_SIZ, "Left scaling vector wrong length");
   if (rr && rr->n != A->n) SETERRQ(PETSC_ERR_ARG_SIZ, "Right scaling vector wrong length");
+  if (blk_on_device(A->A)) { /* MatDiagonalScale_SeqAIJ aij.c:2200-2235 on the device: rows by l, then entries by r[col] */
+    CHKPHIP(phip_mat_diagonal_scale(A->A.dev, ll ? ll->d : NULL, rr ? rr->d : NULL));
+    A->A.host_stale = true;
+    return 0;
+  }
   const PetscScalar *l = NULL, *r = NULL;
-  PetscErrorCode     ierr;
+  PetscErrorCode     ierr = A->A.sync_host(); CHKERRQ(ierr);
   if (ll) { ierr = VecGetArrayRead(ll, &l); CHKERRQ(ierr); }
   if (rr && rr != ll) { ierr = VecGetArrayRead(rr, &r); CHKERRQ(ierr); } else if (rr) r = l;
   aij_diagonal_scale(A->A, l, r);
@@ -1632,13 +1666,20 @@ static PetscErrorCode MatDiagonalScale_MPIAIJHIP(Mat A, Vec ll, Vec rr)
 {
   if (rr && rr->n != A->n) SETERRQ(PETSC_ERR_ARG_SIZ, "right vector non-conforming local size");
   if (ll && ll->n != A->m) SETERRQ(PETSC_ERR_ARG_SIZ, "left vector non-conforming local size");
-  PetscErrorCode      ierr;
-  std::vector<double> ghost(A->garray.size() + 1);
-  if (rr) {
+  PetscErrorCode ierr;
+  if (rr) { /* collective: every rank exchanges, whether or not its blocks can take the update on the device */
     CHKPHIP(phip_halo_begin(A->halo, rr->d, A->lvec));
     CHKPHIP(phip_halo_end(A->halo));
-    if (!A->garray.empty()) CHKPHIP(phip_memcpy_d2h(MCTX(A), ghost.data(), A->lvec, sizeof(double) * A->garray.size()));
   }
+  if (blk_on_device(A->A) && blk_on_device(A->B)) { /* mpiaij.c:2040-2069 on the device; the off-diagonal block's columns are the ghost entries of lvec */
+    CHKPHIP(phip_mat_diagonal_scale(A->B.dev, ll ? ll->d : NULL, rr ? A->lvec : NULL));
+    CHKPHIP(phip_mat_diagonal_scale(A->A.dev, ll ? ll->d : NULL, rr ? rr->d : NULL));
+    A->A.host_stale = A->B.host_stale = true;
+    return 0;
+  }
+  ierr = mat_sync_host(A); CHKERRQ(ierr);
+  std::vector<double> ghost(A->garray.size() + 1);
+  if (rr && !A->garray.empty()) CHKPHIP(phip_memcpy_d2h(MCTX(A), ghost.data(), A->lvec, sizeof(double) * A->garray.size()));
   const PetscScalar *l = NULL, *r = NULL;
   if (ll) { ierr = VecGetArrayRead(ll, &l); CHKERRQ(ierr); }
   if (rr && rr != ll) { ierr = VecGetArrayRead(rr, &r); CHKERRQ(ierr); } else if (rr) r = l;
@@ -1733,6 +1774,7 @@ extern "C" PetscErrorCode MatSetUp(Mat A)
 }
 extern "C" PetscErrorCode MatSetValues(Mat A, PetscInt m, const PetscInt idxm[], PetscInt n, const PetscInt idxn[], const PetscScalar v[], InsertMode addv)
 {
+  if (A && (A->A.host_stale || A->B.host_stale)) { PetscErrorCode serr = mat_sync_host(A); CHKERRQ(serr); }
   MatCheck(A, "MatSetValues");
   if (!m || !n) return 0;
   if (!A->preallocated) { PetscErrorCode ierr = MatSetUp(A); CHKERRQ(ierr); }
@@ -1761,6 +1803,7 @@ extern "C" PetscErrorCode MatZeroRows(Mat A, PetscInt numRows, const PetscInt ro
 {
   MatCheckAssembled(A, "MatZeroRows");
   if (x || b) SETERRQ(PETSC_ERR_SUP, "MatZeroRows: fixing the right-hand side (x, b non-NULL) is not supported");
+  { PetscErrorCode serr = mat_sync_host(A); CHKERRQ(serr); }
   const PetscInt rstart = A->rrange[(size_t)A->comm->rank], rend = A->rrange[(size_t)A->comm->rank + 1];
   for (PetscInt k = 0; k < numRows; k++) {
     if (rows[k] < 0 || rows[k] >= A->M) SETERRQ(PETSC_ERR_ARG_OUTOFRANGE, "Row %d out of range", rows[k]);
@@ -1877,6 +1920,18 @@ static PetscErrorCode MatShift_AIJHIP(Mat A, PetscScalar a)
 {
   const PetscInt rstart = A->rrange[(size_t)A->comm->rank], rend = A->rrange[(size_t)A->comm->rank + 1];
   PetscErrorCode ierr;
+  /* every owned row stores its diagonal entry (in the diagonal block): the pattern stays, the addition runs on the device.  Collective
+     decision: a rank that must insert entries re-assembles, and assembly is collective (stash exchange). */
+  int mine = blk_on_device(A->A) && (!A->mpi || rstart == A->crange[(size_t)A->comm->rank]) && A->m <= A->n;
+  for (PetscInt r = 0; mine && r < A->m; r++) mine = A->A.diag[(size_t)r] < A->A.ai[(size_t)r + 1];
+  double all = mine ? 0.0 : 1.0;
+  if (A->mpi) CHKPHIP(phip_comm_allreduce_host(A->comm->comm, &all, 1, 1));
+  if (all == 0.0) {
+    CHKPHIP(phip_mat_shift(A->A.dev, a));
+    A->A.host_stale = true;
+    A->state++;
+    return 0;
+  }
   for (PetscInt i = rstart; i < rend; i++) { ierr = MatSetValues(A, 1, &i, 1, &i, &a, ADD_VALUES); CHKERRQ(ierr); }
   ierr = MatAssemblyBegin(A, MAT_FINAL_ASSEMBLY); CHKERRQ(ierr);
   return MatAssemblyEnd(A, MAT_FINAL_ASSEMBLY);
@@ -1947,6 +2002,7 @@ extern "C" PetscErrorCode MatGetRowMaxAbs(Mat A, Vec v, PetscInt idx[])
 {
   MatCheckAssembled(A, "MatGetRowMaxAbs"); VecCheckReady(v, "MatGetRowMaxAbs");
   if (idx) SETERRQ(PETSC_ERR_SUP, "MatGetRowMaxAbs: returning the column indices is not supported");
+  { PetscErrorCode serr = mat_sync_host(A); CHKERRQ(serr); }
   if (v->n != A->m) SETERRQ(PETSC_ERR_ARG_SIZ, "Nonconforming matrix and vector");
   PetscScalar   *x;
   PetscErrorCode ierr = VecGetArray(v, &x); CHKERRQ(ierr);
@@ -1989,6 +2045,7 @@ extern "C" PetscErrorCode MatHipGetBlockInfo(Mat A, int which, PetscInt *m, Pets
 }
 extern "C" PetscErrorCode MatHipGetBlockArrays(Mat A, int which, PetscInt *i, PetscInt *j, PetscScalar *a, PetscInt *diag, PetscInt *cprow_i, PetscInt *cprow_rindex)
 {
+  if (A && (A->A.host_stale || A->B.host_stale)) { PetscErrorCode serr = mat_sync_host(A); CHKERRQ(serr); }
   MatCheckAssembled(A, "MatHipGetBlockArrays");
   if (which == 1 && !A->mpi) SETERRQ(PETSC_ERR_ARG_WRONG, "MatHipGetBlockArrays: a Seq matrix has no off-diagonal block");
   const HostAIJ &H = which ? A->B : A->A;
@@ -2170,6 +2227,7 @@ extern "C" PetscErrorCode VecLoad(Vec v, const char *filename, int64_t *offset)
 /* MatView_SeqAIJ_Binary aij.c:547-582 / MatView_MPIAIJ_Binary mpiaij.c:1180-1330: ranks append their parts in rank order */
 extern "C" PetscErrorCode MatView(Mat A, const char *filename, int append)
 {
+  if (A && (A->A.host_stale || A->B.host_stale)) { PetscErrorCode serr = mat_sync_host(A); CHKERRQ(serr); }
   MatCheckAssembled(A, "MatView");
   const int size = A->comm->size, rank = A->comm->rank;
   PetscInt  lnz = A->A.nz + (A->mpi ? A->B.nz : 0);

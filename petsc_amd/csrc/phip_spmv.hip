@@ -1548,6 +1548,150 @@ extern "C" int phip_mat_update_values(phip_mat A, const double *h_a)
   return 0;
 }
 
+/* ---- value updates on the device --------------------------------------------------------------------------------------------------
+   MatScale / MatShift / MatDiagonalScale / MatZeroEntries keep the nonzero pattern, so nothing but values has to change, and the
+   values are on the device already: the kernels below update the CSR values in place, refresh the SELL-dict copy from them (an entry's
+   place in it follows from its row and slot, no map is stored), and carry the change into the pair dictionary and the diagonal masks
+   where that is exact -- scaling multiplies the table's values exactly as it multiplies the entries they stand for, a shift adds to
+   the pairs on diagonal 0 -- or drop the dictionary (diagonal scaling makes the values depend on the position: the matrix then streams
+   its values, 9 B/nz).  The transposed copy follows.  No value crosses PCIe; the host CSR of the caller is brought up to date with
+   phip_mat_get_values when (if) the host asks for values again.  Round 1 did all of this on the host and re-sent every value. */
+__global__ __launch_bounds__(PHIP_THREADS) void mat_scale_values_kernel(int64_t n, double *__restrict__ v, double alpha)
+{
+  const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; i < n; i += stride) v[i] = v[i] * alpha;
+}
+
+/* a[k] = (a[k] * l[row]) * r[col[k]]: the two loops of MatDiagonalScale_SeqAIJ (aij.c:2214-2228), two roundings per entry; l or r may be NULL */
+__global__ __launch_bounds__(PHIP_THREADS) void mat_diagonal_scale_kernel(int32_t R, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx, int cprow,
+                                                                         const int32_t *__restrict__ col, double *__restrict__ val, const double *__restrict__ l,
+                                                                         const double *__restrict__ r, int colfirst)
+{
+  const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
+  for (int64_t q = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; q < R; q += stride) {
+    const double lv = l ? l[cprow ? ridx[q] : (int32_t)q] : 1.0;
+    for (int32_t k = rowptr[q]; k < rowptr[q + 1]; k++) {
+      double a = val[k];
+      if (colfirst) { /* the transposed copy: its column factor is the original's row factor, which the reference applies first */
+        if (r) a = a * r[col[k]];
+        if (l) a = a * lv;
+      } else {
+        if (l) a = a * lv;
+        if (r) a = a * r[col[k]];
+      }
+      val[k] = a;
+    }
+  }
+}
+
+/* a[k] += alpha where col[k] == row (MatShift_Basic, gcreate.c:6-24, on a matrix whose rows hold their diagonal entries) */
+__global__ __launch_bounds__(PHIP_THREADS) void mat_shift_kernel(int32_t R, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx, int cprow,
+                                                                const int32_t *__restrict__ col, double *__restrict__ val, double alpha)
+{
+  const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
+  for (int64_t q = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; q < R; q += stride) {
+    const int32_t i = cprow ? ridx[q] : (int32_t)q;
+    for (int32_t k = rowptr[q]; k < rowptr[q + 1]; k++)
+      if (col[k] == i) { val[k] = val[k] + alpha; break; }
+  }
+}
+
+/* the SELL-dict values out of the CSR values: entry sl of row r lives at sptr[r / 512] + r % 512 + 512 sl */
+__global__ __launch_bounds__(PHIP_THREADS) void sell_refresh_values_kernel(int32_t m, const int32_t *__restrict__ rowptr, const double *__restrict__ val,
+                                                                          const int64_t *__restrict__ sptr, double *__restrict__ sval)
+{
+  const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
+  for (int64_t r = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; r < m; r += stride) {
+    const int64_t pos0 = sptr[r / SELL_H] + (r % SELL_H);
+    const int32_t k0 = rowptr[r], len = rowptr[r + 1] - k0;
+    for (int32_t sl = 0; sl < len; sl++) sval[pos0 + (int64_t)sl * SELL_H] = val[k0 + sl];
+  }
+}
+
+/* the pair tables after a shift: the pairs on diagonal 0 stand for the diagonal entries */
+__global__ void pair_table_shift_kernel(int n, const int32_t *__restrict__ offs, double *__restrict__ vals, double alpha)
+{
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n && offs[q] == 0) vals[q] = vals[q] + alpha;
+}
+
+static int dev_grid(int64_t n) { return phip_grid_for(n, 1, 8192); }
+
+static int refresh_sell_values(phip_mat A)
+{
+  if (!A->sell_built) return 0;
+  hipLaunchKernelGGL(sell_refresh_values_kernel, dim3(dev_grid(A->m)), dim3(PHIP_THREADS), 0, A->ctx->stream, A->m, A->d_rowptr, A->d_val, A->d_sptr, A->d_sval);
+  PHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+#define MAT_DEV_ENTER(A, name)                                                                        \
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, name ": null matrix");                                           \
+  PHIP_NEED_DEVICE((A)->ctx, name);                                                                   \
+  PHIP_FLUSH((A)->ctx);                                                                               \
+  PHIP_CHECK_HIP(hipSetDevice((A)->ctx->device))
+
+extern "C" int phip_mat_scale(phip_mat A, double alpha)
+{
+  MAT_DEV_ENTER(A, "phip_mat_scale");
+  hipStream_t st = A->ctx->stream;
+  if (A->nnz) hipLaunchKernelGGL(mat_scale_values_kernel, dim3(dev_grid(A->nnz)), dim3(PHIP_THREADS), 0, st, A->nnz, A->d_val, alpha);
+  if (A->sell_built) hipLaunchKernelGGL(mat_scale_values_kernel, dim3(dev_grid(A->sell_padded)), dim3(PHIP_THREADS), 0, st, A->sell_padded, A->d_sval, alpha);
+  if (A->vd_built) hipLaunchKernelGGL(mat_scale_values_kernel, dim3(1), dim3(PHIP_THREADS), 0, st, (int64_t)SELL_MAX_OFFS, A->d_svtab, alpha);
+  if (A->dm_built) hipLaunchKernelGGL(mat_scale_values_kernel, dim3(1), dim3(PHIP_THREADS), 0, st, (int64_t)DMASK_MAX_PAIRS, A->d_dmvals, alpha);
+  PHIP_CHECK_HIP(hipGetLastError());
+  return A->T ? phip_mat_scale(A->T, alpha) : 0;
+}
+
+extern "C" int phip_mat_shift(phip_mat A, double alpha)
+{
+  MAT_DEV_ENTER(A, "phip_mat_shift");
+  hipStream_t st = A->ctx->stream;
+  if (A->R) hipLaunchKernelGGL(mat_shift_kernel, dim3(dev_grid(A->R)), dim3(PHIP_THREADS), 0, st, A->R, A->d_rowptr, A->d_ridx, A->use_cprow, A->d_col, A->d_val, alpha);
+  PHIP_CHECK_HIP(hipGetLastError());
+  int rc = refresh_sell_values(A);
+  if (rc) return rc;
+  if (A->vd_built) hipLaunchKernelGGL(pair_table_shift_kernel, dim3(1), dim3(SELL_MAX_OFFS), 0, st, A->vd_npairs, A->d_spoffs, A->d_svtab, alpha);
+  if (A->dm_built) hipLaunchKernelGGL(pair_table_shift_kernel, dim3(1), dim3(DMASK_MAX_PAIRS), 0, st, A->dm_npairs, A->d_dmoffs, A->d_dmvals, alpha);
+  PHIP_CHECK_HIP(hipGetLastError());
+  return A->T ? phip_mat_shift(A->T, alpha) : 0;
+}
+
+static int mat_diagonal_scale_impl(phip_mat A, const double *d_l, const double *d_r, int colfirst)
+{
+  MAT_DEV_ENTER(A, "phip_mat_diagonal_scale");
+  if (!d_l && !d_r) return 0;
+  hipStream_t st = A->ctx->stream;
+  if (A->R) hipLaunchKernelGGL(mat_diagonal_scale_kernel, dim3(dev_grid(A->R)), dim3(PHIP_THREADS), 0, st, A->R, A->d_rowptr, A->d_ridx, A->use_cprow, A->d_col, A->d_val, d_l, d_r, colfirst);
+  PHIP_CHECK_HIP(hipGetLastError());
+  int rc = refresh_sell_values(A);
+  if (rc) return rc;
+  if (A->vd_built) { PHIP_CHECK_HIP(hipStreamSynchronize(st)); free_pairs(A); } /* the values now depend on the position: streamed from here on */
+  return A->T ? mat_diagonal_scale_impl(A->T, d_r, d_l, !colfirst) : 0;
+}
+
+extern "C" int phip_mat_diagonal_scale(phip_mat A, const double *d_l, const double *d_r) { return mat_diagonal_scale_impl(A, d_l, d_r, 0); }
+
+extern "C" int phip_mat_zero_entries(phip_mat A)
+{
+  MAT_DEV_ENTER(A, "phip_mat_zero_entries");
+  hipStream_t st = A->ctx->stream;
+  if (A->nnz) PHIP_CHECK_HIP(hipMemsetAsync(A->d_val, 0, sizeof(double) * (size_t)A->nnz, st));
+  if (A->sell_built) PHIP_CHECK_HIP(hipMemsetAsync(A->d_sval, 0, sizeof(double) * (size_t)A->sell_padded, st));
+  if (A->vd_built) PHIP_CHECK_HIP(hipMemsetAsync(A->d_svtab, 0, sizeof(double) * SELL_MAX_OFFS, st));
+  if (A->dm_built) PHIP_CHECK_HIP(hipMemsetAsync(A->d_dmvals, 0, sizeof(double) * DMASK_MAX_PAIRS, st));
+  return A->T ? phip_mat_zero_entries(A->T) : 0;
+}
+
+extern "C" int phip_mat_get_values(phip_mat A, double *h_a)
+{
+  MAT_DEV_ENTER(A, "phip_mat_get_values");
+  PHIP_REQUIRE(h_a || !A->nnz, PHIP_ERR_ARG_NULL, "phip_mat_get_values: null array");
+  if (A->nnz) PHIP_CHECK_HIP(hipMemcpyAsync(h_a, A->d_val, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToHost, A->ctx->stream));
+  PHIP_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
+  return 0;
+}
+
 extern "C" int phip_mat_destroy(phip_mat A)
 {
   if (!A) return 0;

@@ -311,6 +311,58 @@ def test_scale_diagonalscale_shift(golden_dir, size):
             assert np.abs(g_ - ref).max() <= 1e-12 * (np.abs(ref).max() + 1e-300)
 
 
+@pytest.mark.parametrize("size", [1, 2])
+def test_value_updates_stay_on_device(size):
+    """MatScale / MatShift / MatDiagonalScale / MatZeroEntries of the HIP types run on the device copy (include/petschip.h "value updates
+    that keep the nonzero pattern"); the host CSR catches up when somebody asks for values: MatHipGetBlockArrays (= what MatGetRow /
+    MatView would read) returns the host loops' bits, a later MatSetValues + MatAssemblyEnd lands on the updated values, and the
+    constant-coefficient layouts (pair dictionary, diagonal masks) survive scale and shift."""
+    import ctypes as C
+    from petsc_amd import capi, generators as G, petsc as P
+    ai, aj, aa = G.laplace3d_7pt(10, 9, 8, dirichlet_rows=False)
+    N = len(ai) - 1
+    L = capi.load()
+
+    def body(comm):
+        rs, re = local_slice(comm, N)
+        A = P.Mat.from_global_csr(comm, ai, aj, aa)
+        before = [A.block(w)["a"].copy() for w in range(2 if comm.size > 1 else 1)]
+        du = C.c_int()
+        L.phip_mat_diag_mask_info(A.device_mat(0), None, C.byref(du), None)
+        assert du.value == 1
+        A.scale(3.0)
+        A.shift(0.5)
+        L.phip_mat_diag_mask_info(A.device_mat(0), None, C.byref(du), None)
+        assert du.value == 1                                    # still the diagonal masks: nothing was rebuilt, nothing re-sent
+        blk = A.block(0)
+        want = before[0] * 3.0
+        dpos = blk["diag"]
+        want[dpos] = want[dpos] + 0.5
+        np.testing.assert_array_equal(blk["a"], want)           # the host copy caught up (phip_mat_get_values)
+        if comm.size > 1:
+            np.testing.assert_array_equal(A.block(1)["a"], before[1] * 3.0)
+        x = P.Vec.from_array(comm, np.ones(re - rs), N)
+        y = x.duplicate()
+        A.mult(x, y)
+        y1 = y.array()
+        A.set_values([rs], [rs], [2.0], P.ADD_VALUES)           # host-side change on top of the device-side ones
+        A.assemble()
+        A.mult(x, y)
+        y2 = y.array()
+        assert y2[0] == y1[0] + 2.0 and np.array_equal(y2[1:], y1[1:])
+        A.zero_entries()
+        A.mult(x, y)
+        assert not y.array().any()
+        for o in (x, y, A):
+            o.destroy()
+        return y1
+
+    import scipy.sparse as sp
+    S = sp.csr_matrix((aa, aj, ai), shape=(N, N)) * 3.0 + 0.5 * sp.identity(N)
+    got = gather(run_ranks(size, body))
+    assert np.abs(got - S @ np.ones(N)).max() <= 1e-12 * np.abs(S @ np.ones(N)).max()
+
+
 def test_ranks_without_rows(orc):
     """More ranks than rows (PetscSplitOwnership gives some ranks nothing, psplit.c:88), a diagonal matrix (no ghost entries anywhere)
     and a matrix whose ranks all talk to all others: products, reductions and a solve still agree with the oracle."""

@@ -994,3 +994,85 @@ def test_batched_elementwise_ops(orc, n):
     big = np.arange(2.0 * n + 8); big[:n] += z; big[1:n + 1] += z; big[:n + 3] *= 2.0
     np.testing.assert_array_equal(got[4], big)
     assert np.abs(got[5] - np.array([w @ w, w @ y, w @ z])).max() <= 1e-12 * max(1.0, (w * w).sum(), np.abs(w * y).sum(), np.abs(w * z).sum())
+
+
+def test_device_side_value_updates(ctx, orc):
+    """phip_mat_scale / phip_mat_shift / phip_mat_diagonal_scale / phip_mat_zero_entries (MatScale_SeqAIJ aij.c:2475-2488, MatShift_Basic
+    gcreate.c:6-24, MatDiagonalScale_SeqAIJ aij.c:2200-2235, MatZeroEntries_SeqAIJ aij.c:1058-1067) change the values where they live, on
+    the device, in every layout at once: the CSR values read back are bit-identical to the host loops' (a * alpha; a(i,i) + alpha;
+    (a * l_i) * r_j), every product afterwards equals the product of a matrix created from those values (bit for bit), the pair
+    dictionary and the diagonal masks survive scaling and shifting, and a diagonal scaling falls back to streamed values."""
+    import ctypes as C
+    from petsc_amd import generators as G
+    L = ctx.lib
+    rng = np.random.default_rng(31)
+
+    def flags(A):
+        f, vb, vu, db, du = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        ctx.check(L.phip_mat_format_info(A, C.byref(f), None, None))
+        ctx.check(L.phip_mat_value_dict_info(A, C.byref(vb), C.byref(vu), None))
+        ctx.check(L.phip_mat_diag_mask_info(A, C.byref(db), C.byref(du), None))
+        return f.value, vu.value, du.value
+
+    def products(A, m, n, x, v):
+        dx, dv, dy, dt = ctx.to_device(x), ctx.to_device(v), ctx.to_device(np.zeros(m)), ctx.to_device(np.zeros(n))
+        ctx.check(L.phip_mat_mult(A, dx, dy))
+        ctx.check(L.phip_mat_mult_transpose(A, dv, dt))
+        out = (ctx.to_host(dy, m), ctx.to_host(dt, n))
+        for p in (dx, dv, dy, dt):
+            ctx.free(p)
+        return out
+
+    def fresh(ci, cj, ca, n, x, v):
+        B = ctx.mat_create(len(ci) - 1, n, ci, cj, ca)
+        ctx.check(L.phip_mat_transpose_setup(B, ci.ctypes.data_as(C.POINTER(C.c_int32)), cj.ctypes.data_as(C.POINTER(C.c_int32)), ca.ctypes.data_as(C.POINTER(C.c_double))))
+        out = products(B, len(ci) - 1, n, x, v)
+        ctx.check(L.phip_mat_destroy(B))
+        return out
+
+    ri, rj, ra = G.rmat(11)
+    cases = [("7-point, diagonal masks", *G.laplace3d_7pt(14, 11, 9, dirichlet_rows=False), (2, 1, 1)),
+             ("convection-diffusion, diagonal masks", *G.convdiff3d_7pt(10, 9, 8), (2, 1, 1)),
+             ("R-MAT, CSR row blocks", ri, rj, ra, (1, 0, 0))]
+    si, sj, sa = G.laplace3d_7pt(12, dirichlet_rows=False)
+    cases.append(("7-point with values of its own, SELL-dict streamed", si, sj, sa * rng.uniform(0.5, 1.5, len(sa)), (2, 0, 0)))
+    for name, ci, cj, ca, want in cases:
+        ci, cj, ca = np.ascontiguousarray(ci, np.int32), np.ascontiguousarray(cj, np.int32), np.ascontiguousarray(ca, np.float64)
+        m = n = len(ci) - 1
+        rows = np.repeat(np.arange(m), np.diff(ci))
+        x, v, l, r = rng.standard_normal(n), rng.standard_normal(m), rng.uniform(0.5, 2.0, m), rng.uniform(0.5, 2.0, n)
+        A = ctx.mat_create(m, n, ci, cj, ca)
+        ctx.check(L.phip_mat_transpose_setup(A, ci.ctypes.data_as(C.POINTER(C.c_int32)), cj.ctypes.data_as(C.POINTER(C.c_int32)), ca.ctypes.data_as(C.POINTER(C.c_double))))
+        assert flags(A) == want, (name, flags(A))
+        cur = ca.copy()
+        got = np.zeros_like(cur)
+
+        def check(tag, keep_layout):
+            ctx.check(L.phip_mat_get_values(A, got.ctypes.data_as(C.POINTER(C.c_double))))
+            np.testing.assert_array_equal(got, cur, err_msg="%s: %s" % (name, tag))
+            if keep_layout:
+                assert flags(A) == want, (name, tag, flags(A))
+            y, t = products(A, m, n, x, v)
+            yf, tf = fresh(ci, cj, cur, n, x, v)
+            np.testing.assert_array_equal(y, yf, err_msg="%s: %s" % (name, tag))
+            np.testing.assert_array_equal(t, tf, err_msg="%s: %s (transpose)" % (name, tag))
+            assert relerr(y, orc.matmult(ci, cj, cur, x)) <= 1e-12
+
+        ctx.check(L.phip_mat_scale(A, 2.5)); cur = cur * 2.5
+        check("scale", True)
+        if np.all(np.isin(np.arange(m), cj[cj == rows])):          # every row stores its diagonal entry
+            ctx.check(L.phip_mat_shift(A, -0.75)); cur[cj == rows] = cur[cj == rows] + -0.75
+            check("shift", True)
+        dl, dr = ctx.to_device(l), ctx.to_device(r)
+        ctx.check(L.phip_mat_diagonal_scale(A, dl, dr)); cur = (cur * l[rows]) * r[cj]
+        check("diagonal scale", False)
+        assert flags(A)[1:] == (0, 0)                               # position-dependent values: no dictionary any more
+        ctx.check(L.phip_mat_diagonal_scale(A, None, dr)); cur = cur * r[cj]
+        ctx.check(L.phip_mat_diagonal_scale(A, dl, None)); cur = cur * l[rows]
+        check("one-sided diagonal scales", False)
+        ctx.check(L.phip_mat_update_values(A, ca.ctypes.data_as(C.POINTER(C.c_double)))); cur = ca.copy()   # the host route brings the dictionary back
+        check("update_values", True)
+        ctx.check(L.phip_mat_zero_entries(A)); cur = np.zeros_like(cur)
+        check("zero entries", False)
+        ctx.free(dl); ctx.free(dr)
+        ctx.check(L.phip_mat_destroy(A))
