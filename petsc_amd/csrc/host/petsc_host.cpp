@@ -1071,6 +1071,7 @@ struct HostAIJ {
   bool     cprow_use = false;
   phip_mat dev = NULL;
   bool     t_ready = false;        /* the device matrix carries its transposed copy (phip_mat_transpose_setup) */
+  bool     dev_numeric = false;    /* dev lives on a GPU (false on a planning-only context: value operations then stay on the host) */
   bool     host_stale = false;     /* MatScale / MatShift / MatDiagonalScale ran on the device: a[] is behind until sync_host() */
   /* bring a[] up to date before the host reads or changes values (the role of MatCUSPCopyFromGPU-style coherence flags, petscimpl.h:749) */
   PetscErrorCode sync_host()
@@ -1206,6 +1207,9 @@ struct HostAIJ {
       CHKPHIP(phip_mat_create(ctx, m, n, ai.data(), j.data(), a.data(), cprow_use ? 1 : 0, (PetscInt)cprow_rindex.size(),
                               cprow_use ? cprow_i.data() : NULL, cprow_use ? cprow_rindex.data() : NULL, &dev));
       dev_nonzerostate = nonzerostate;
+      int devno = -1;
+      CHKPHIP(phip_device_info(ctx, &devno, NULL, NULL, NULL, 0));
+      dev_numeric = devno >= 0; /* a planning-only context keeps the values on the host */
     }
     values_dirty = false;
     return 0;
@@ -1367,7 +1371,7 @@ static PetscErrorCode MatZeroEntries_AIJHIP(Mat A) /* MatZeroEntries_SeqAIJ aij.
   for (int w = 0; w < (A->mpi ? 2 : 1); w++) {
     std::fill(blk[w]->a.begin(), blk[w]->a.end(), 0.0);
     blk[w]->host_stale = false;
-    if (blk[w]->dev && blk[w]->assembled && blk[w]->dev_nonzerostate == blk[w]->nonzerostate && !blk[w]->values_dirty) CHKPHIP(phip_mat_zero_entries(blk[w]->dev));
+    if (blk[w]->dev && blk[w]->dev_numeric && blk[w]->assembled && blk[w]->dev_nonzerostate == blk[w]->nonzerostate && !blk[w]->values_dirty) CHKPHIP(phip_mat_zero_entries(blk[w]->dev));
     else blk[w]->values_dirty = true;
   }
   return 0;
@@ -1393,7 +1397,7 @@ static PetscErrorCode mat_upload_values(Mat A)
   return 0;
 }
 /* is the device copy of the block current, so that a value update can run there? */
-static bool blk_on_device(const HostAIJ &B) { return B.dev && B.assembled && B.dev_nonzerostate == B.nonzerostate && !B.values_dirty; }
+static bool blk_on_device(const HostAIJ &B) { return B.dev && B.dev_numeric && B.assembled && B.dev_nonzerostate == B.nonzerostate && !B.values_dirty; }
 
 static PetscErrorCode MatScale_AIJHIP(Mat A, PetscScalar a) /* aij.c:2475 / MatScale_MPIAIJ mpiaij.c:1139-1148: both blocks, on the device */
 {
