@@ -256,6 +256,9 @@ int phip_vec_mdot_static(void *stream, int32_t n, const double *d_x, int32_t nv,
 typedef struct { int32_t slot, nvals; uint64_t seq; } phip_ticket;
 /* w = x .* y (VecPointwiseMult_Seq bvec2.c:84-110, w aliasing neither x nor y); values {sum w^2, sum w x, sum w y} */
 int phip_vec_pointwise_mult_reduce(phip_ctx ctx, int32_t n, double *d_w, const double *d_x, const double *d_y, int publish, phip_ticket *t);
+/* x += sum_k alpha_k y_k (phip_vec_maxpy, nv >= 1); value {sum x_new^2}: the VecNorm of the VecNormalize that follows the
+ * orthogonalisation in KSPGMRESCycle (gmres.c:170-176 after borthog2.c:60-67) without another pass over x */
+int phip_vec_maxpy_reduce(phip_ctx ctx, int32_t n, double *d_x, int32_t nv, const double *h_alpha, const double *const *h_dy, int publish, phip_ticket *t);
 /* y = A x (phip_mat_mult); value {sum_i v_i y_i}, d_v has m entries (the caller passes x for a square matrix) */
 int phip_mat_mult_dot(phip_mat A, const double *d_x, double *d_y, const double *d_v, int publish, phip_ticket *t);
 /* y += A x in place (phip_mat_multadd with z == y, mpiaij.c:996); adds sum_i v_i (y_new_i - y_old_i) to the value of the live ticket t;

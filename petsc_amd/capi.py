@@ -85,6 +85,7 @@ SIGNATURES = [
     ("phip_vec_swap", C.c_int, [_vp, C.c_int32, _vp, _vp]),
     ("phip_vec_reciprocal", C.c_int, [_vp, C.c_int32, _vp]),
     ("phip_vec_pointwise_mult_reduce", C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, C.c_int, _vp]),
+    ("phip_vec_maxpy_reduce", C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _pD, C.POINTER(_vp), C.c_int, _vp]),
     ("phip_mat_mult_dot", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
     ("phip_mat_multadd_dot", C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
     ("phip_ticket_values", C.c_int, [_vp, _vp, C.POINTER(_vp)]),

@@ -60,8 +60,8 @@ struct _p_PetscComm {
      productions in a row that nobody consumed (GMRES never asks for them) and on again when a request comes that it would have served */
   bool      host_reduce; /* distributed reductions combine on the host (phip_comm_allreduce_host) instead of ncclAllReduce on the device */
   bool      bp_allowed;
-  bool      bp_on[3];
-  int       bp_streak[3];
+  bool      bp_on[4];
+  int       bp_streak[4];
   _p_PetscComm *root; /* the world communicator that owns the switches (self shares them) */
   struct SplitReduction *split; /* VecDotBegin/VecNormBegin ... queue (comb.c), made on first use */
 };
@@ -82,7 +82,7 @@ extern "C" PetscErrorCode PetscHipInitialize(int device, const char *backend, co
   CHKPHIP(phip_comm_create(w->ctx, "self", NULL, 1, 0, &s->comm));
   s->self = s; w->self = s;
   w->root = w; s->root = w;
-  w->bp_allowed = true; w->bp_on[1] = w->bp_on[2] = true;
+  w->bp_allowed = true; w->bp_on[1] = w->bp_on[2] = w->bp_on[3] = true;
   w->host_reduce = !(getenv("PETSCHIP_DEVICE_ALLREDUCE") && atoi(getenv("PETSCHIP_DEVICE_ALLREDUCE")));
   *world = w;
   return 0;
@@ -102,8 +102,8 @@ extern "C" PetscErrorCode PetscHipSetByProducts(PetscComm comm, PetscBool flg)
 {
   if (!comm) SETERRQ(PETSC_ERR_ARG_NULL, "PetscHipSetByProducts: null communicator");
   BP(comm)->bp_allowed = flg != 0;
-  BP(comm)->bp_on[1] = BP(comm)->bp_on[2] = flg != 0;
-  BP(comm)->bp_streak[1] = BP(comm)->bp_streak[2] = 0;
+  BP(comm)->bp_on[1] = BP(comm)->bp_on[2] = BP(comm)->bp_on[3] = flg != 0;
+  BP(comm)->bp_streak[1] = BP(comm)->bp_streak[2] = BP(comm)->bp_streak[3] = 0;
   return 0;
 }
 
@@ -396,10 +396,10 @@ static bool bp_try_dot(Vec x, Vec y, PetscScalar *val)
 }
 static bool bp_try_norm2(Vec w, PetscReal *val)
 {
-  if (w->bp.kind != 1 || w->bp.self_state != w->state) return false;
+  if ((w->bp.kind != 1 && w->bp.kind != 3) || w->bp.self_state != w->state) return false; /* kind 3: sum w^2 alone (VecMAXPY) */
   if (!w->bp.live) {
     PetscComm r = BP(w->comm);
-    if (r->bp_allowed) { r->bp_on[1] = true; r->bp_streak[1] = 0; }
+    if (r->bp_allowed) { r->bp_on[w->bp.kind] = true; r->bp_streak[w->bp.kind] = 0; }
     return false;
   }
   if (!bp_fetch(w)) return false;
@@ -476,6 +476,17 @@ static PetscErrorCode VecMAXPY_HIP(Vec y, PetscInt nv, const PetscScalar *al, Ve
 {
   std::vector<const double *> p((size_t)nv);
   for (PetscInt k = 0; k < nv; k++) p[(size_t)k] = x[k]->d;
+  /* the orthogonalisation's VecMAXPY is followed by VecNormalize (gmres.c:170-176): its sum of squares leaves with the update */
+  if (nv >= 1) {
+    const bool want = bp_want(y, 3);
+    if (want) {
+      phip_ticket t;
+      CHKPHIP(phip_vec_maxpy_reduce(VCTX(y), y->n, y->d, nv, al, p.data(), y->comm->size == 1 || BP(y->comm)->host_reduce, &t));
+      bp_record(y, 3, true, &t, NULL, NULL);
+      return 0;
+    }
+    bp_record(y, 3, false, NULL, NULL, NULL);
+  }
   CHKPHIP(phip_vec_maxpy(VCTX(y), y->n, y->d, nv, al, p.data()));
   return 0;
 }

@@ -24,6 +24,7 @@
 #include <string.h>
 #include <rccl/rccl.h>
 #include <stdlib.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
@@ -202,41 +203,50 @@ static uint64_t hr_hash(const void *id128, int nranks)
   h ^= (uint64_t)nranks; h *= 1099511628211ull;
   return h;
 }
-/* processes of one node: rank 0 creates the segment, the others open it once it exists; the name dies after the first round */
+/* processes of one node: rank 0 creates the segment, the others open it once it exists; the name dies after the first round.
+   Header words: [0] HR_MAGIC once the segment is ready, [1] the creator's pid.  A run that died during set-up leaves its segment
+   behind under the same name: rank 0 unlinks and recreates it, and the other ranks take a segment only while its creator is alive,
+   so one that was opened before rank 0 replaced it is dropped and the name looked up again. */
 static int hr_attach_shm(phip_comm c, const void *id128)
 {
   HostRing *r = &c->hr;
   r->bytes = HR_HEADER + hr_bytes(c->size);
   snprintf(r->name, sizeof(r->name), "/phip_%016llx", (unsigned long long)hr_hash(id128, c->size));
-  int fd = -1;
+  void *mem = MAP_FAILED;
   if (c->rank == 0) {
     shm_unlink(r->name); /* a leftover of a run that died under the same key */
-    fd = shm_open(r->name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    int fd = shm_open(r->name, O_CREAT | O_EXCL | O_RDWR, 0600);
     PHIP_REQUIRE(fd >= 0, PHIP_ERR_LIB, "phip_comm_create: shm_open(%s) failed: %s", r->name, strerror(errno));
     if (ftruncate(fd, (off_t)r->bytes)) { close(fd); shm_unlink(r->name); PHIP_REQUIRE(0, PHIP_ERR_LIB, "phip_comm_create: ftruncate(%s): %s", r->name, strerror(errno)); }
+    mem = mmap(NULL, r->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (mem == MAP_FAILED) { shm_unlink(r->name); PHIP_REQUIRE(0, PHIP_ERR_LIB, "phip_comm_create: mmap(%s): %s", r->name, strerror(errno)); }
+    ((uint64_t *)mem)[1] = (uint64_t)getpid();
+    __atomic_store_n((uint64_t *)mem, HR_MAGIC, __ATOMIC_RELEASE); /* a fresh segment is zero-filled */
   } else {
     const double t0 = hr_now();
     for (;;) {
-      fd = shm_open(r->name, O_RDWR, 0600);
+      int fd = shm_open(r->name, O_RDWR, 0600);
       if (fd >= 0) {
         struct stat st;
-        if (!fstat(fd, &st) && (size_t)st.st_size == r->bytes) break;
-        close(fd); fd = -1;
+        if (!fstat(fd, &st) && (size_t)st.st_size == r->bytes) {
+          mem = mmap(NULL, r->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+          if (mem != MAP_FAILED) {
+            if (__atomic_load_n((const uint64_t *)mem, __ATOMIC_ACQUIRE) == HR_MAGIC) {
+              const pid_t creator = (pid_t)((const uint64_t *)mem)[1];
+              if (creator > 0 && (kill(creator, 0) == 0 || errno == EPERM)) { close(fd); break; }
+            }
+            munmap(mem, r->bytes); mem = MAP_FAILED; /* not ready yet, or the leftover of a dead run */
+          }
+        }
+        close(fd);
       }
       PHIP_REQUIRE(hr_now() - t0 < hr_timeout(), PHIP_ERR_LIB, "phip_comm_create: rank 0 never created %s (ranks on different nodes?)", r->name);
       usleep(200);
     }
   }
-  void *mem = mmap(NULL, r->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (mem == MAP_FAILED) { if (c->rank == 0) shm_unlink(r->name); PHIP_REQUIRE(0, PHIP_ERR_LIB, "phip_comm_create: mmap(%s): %s", r->name, strerror(errno)); }
   r->slots = (HostRingSlot *)((char *)mem + HR_HEADER);
   r->is_shm = 1; r->round = 0;
-  if (c->rank == 0) __atomic_store_n((uint64_t *)mem, HR_MAGIC, __ATOMIC_RELEASE); /* a fresh segment is zero-filled */
-  else {
-    int rc = hr_wait((const uint64_t *)mem, HR_MAGIC, "phip_comm_create", 0);
-    if (rc) return rc;
-  }
   return 0;
 }
 static void hr_detach(phip_comm c)

@@ -99,14 +99,16 @@ __global__ __launch_bounds__(PHIP_THREADS) void norm_kernel(int32_t n, const dou
   }
 }
 
-/* x += sum_k a_k y_k : x read and written once per launch */
-template <int NV>
-__global__ __launch_bounds__(PHIP_THREADS) void maxpy_kernel(int32_t n, double *__restrict__ x, MVPack P)
+/* x += sum_k a_k y_k : x read and written once per launch.  RED: the by-product sum x_new^2 (the VecNorm of the VecNormalize that
+   follows the orthogonalisation, gmres.c:170-176 after borthog2.c:60-67) leaves through ctl; grid <= PHIP_RED_BLOCKS then */
+template <int NV, bool RED = false>
+__global__ __launch_bounds__(PHIP_THREADS) void maxpy_kernel(int32_t n, double *__restrict__ x, MVPack P, RedCtl ctl)
 {
   constexpr bool nt = NV >= MV_NT_MIN; /* as in mdot_kernel (192^3: maxpy16 198 -> 165 us together with the larger grid; maxpy2 32.7 -> 35.7 us, hence the limit) */
   const int64_t n2 = n >> 1;
   const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
   typedef double v2d __attribute__((ext_vector_type(2)));
+  double sq[1] = {0.0};
   for (int64_t i = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; i < n2; i += stride) {
     double2 xv = reinterpret_cast<double2 *>(x)[i];
 #pragma unroll
@@ -118,12 +120,20 @@ __global__ __launch_bounds__(PHIP_THREADS) void maxpy_kernel(int32_t n, double *
       xv.y += P.a[k] * yv.y;
     }
     reinterpret_cast<double2 *>(x)[i] = xv;
+    if (RED) sq[0] += xv.x * xv.x + xv.y * xv.y;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     double v = x[n - 1];
 #pragma unroll
     for (int k = 0; k < NV; k++) v += P.a[k] * P.y[k][n - 1];
     x[n - 1] = v;
+    if (RED) sq[0] += v * v;
+  }
+  if (RED) {
+    __shared__ double lds[4];
+    block_sum<1>(sq, lds);
+    __syncthreads();
+    reduce_tail<1, 0>(sq, lds, ctl);
   }
 }
 
@@ -798,11 +808,34 @@ extern "C" int phip_vec_norm(phip_ctx c, int32_t n, const double *d_x, int type,
 }
 
 template <int NV>
-static void launch_maxpy(phip_ctx c, int32_t n, double *d_x, const MVPack &P)
+static void launch_maxpy(phip_ctx c, int32_t n, double *d_x, const MVPack &P, const RedCtl *ctl)
 {
   /* one entry pair per thread and a large grid for the long lists (maxpy16 at 192^3: 2048 workgroups 198 us, 16384 187 us) */
   const int grid = NV >= MV_NT_MIN ? phip_grid_for((int64_t)n / 2 + 1, 1, 16384) : EW_GRID(n);
-  hipLaunchKernelGGL((maxpy_kernel<NV>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, P);
+  if (ctl) hipLaunchKernelGGL((maxpy_kernel<NV, true>), dim3(grid < PHIP_RED_BLOCKS ? grid : PHIP_RED_BLOCKS), dim3(PHIP_THREADS), 0, c->stream, n, d_x, P, *ctl);
+  else hipLaunchKernelGGL((maxpy_kernel<NV, false>), dim3(grid), dim3(PHIP_THREADS), 0, c->stream, n, d_x, P, RedCtl());
+}
+
+/* the launches of one VecMAXPY; with ctl the last of them carries the by-product */
+static int maxpy_groups(phip_ctx c, int32_t n, double *d_x, int32_t nv, const double *h_alpha, const double *const *h_dy, const RedCtl *ctl)
+{
+  const int ngroups = (nv + MV_MAX - 1) / MV_MAX; /* balanced groups: x is read and written once per group */
+  for (int gi = 0, k0 = 0; gi < ngroups; gi++) {
+    const int g = (nv - k0 + (ngroups - gi) - 1) / (ngroups - gi);
+    MVPack    P;
+    for (int k = 0; k < MV_MAX; k++) { P.y[k] = (k < g) ? h_dy[k0 + k] : d_x; P.a[k] = (k < g) ? h_alpha[k0 + k] : 0.0; }
+    const RedCtl *cl = (gi == ngroups - 1) ? ctl : NULL;
+    switch (g) {
+#define MAXPY_CASE(N) case N: launch_maxpy<N>(c, n, d_x, P, cl); break;
+      MAXPY_CASE(1) MAXPY_CASE(2) MAXPY_CASE(3) MAXPY_CASE(4) MAXPY_CASE(5) MAXPY_CASE(6) MAXPY_CASE(7) MAXPY_CASE(8)
+      MAXPY_CASE(9) MAXPY_CASE(10) MAXPY_CASE(11) MAXPY_CASE(12) MAXPY_CASE(13) MAXPY_CASE(14) MAXPY_CASE(15)
+#undef MAXPY_CASE
+    default: launch_maxpy<16>(c, n, d_x, P, cl); break;
+    }
+    k0 += g;
+    PHIP_CHECK_HIP(hipGetLastError());
+  }
+  return 0;
 }
 
 extern "C" int phip_vec_maxpy(phip_ctx c, int32_t n, double *d_x, int32_t nv, const double *h_alpha, const double *const *h_dy)
@@ -810,23 +843,21 @@ extern "C" int phip_vec_maxpy(phip_ctx c, int32_t n, double *d_x, int32_t nv, co
   CHECK_CTX(c, "phip_vec_maxpy"); CHECK_N(n, "phip_vec_maxpy");
   PHIP_REQUIRE(nv >= 0, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_maxpy: nv=%d", nv);
   PHIP_REQUIRE((h_alpha && h_dy) || !nv, PHIP_ERR_ARG_NULL, "phip_vec_maxpy: null argument");
-  if (!n) return 0;
-  const int ngroups = (nv + MV_MAX - 1) / MV_MAX; /* balanced groups: x is read and written once per group */
-  for (int gi = 0, k0 = 0; gi < ngroups; gi++) {
-    const int g = (nv - k0 + (ngroups - gi) - 1) / (ngroups - gi);
-    MVPack    P;
-    for (int k = 0; k < MV_MAX; k++) { P.y[k] = (k < g) ? h_dy[k0 + k] : d_x; P.a[k] = (k < g) ? h_alpha[k0 + k] : 0.0; }
-    switch (g) {
-#define MAXPY_CASE(N) case N: launch_maxpy<N>(c, n, d_x, P); break;
-      MAXPY_CASE(1) MAXPY_CASE(2) MAXPY_CASE(3) MAXPY_CASE(4) MAXPY_CASE(5) MAXPY_CASE(6) MAXPY_CASE(7) MAXPY_CASE(8)
-      MAXPY_CASE(9) MAXPY_CASE(10) MAXPY_CASE(11) MAXPY_CASE(12) MAXPY_CASE(13) MAXPY_CASE(14) MAXPY_CASE(15)
-#undef MAXPY_CASE
-    default: launch_maxpy<16>(c, n, d_x, P); break;
-    }
-    k0 += g;
-    PHIP_CHECK_HIP(hipGetLastError());
-  }
-  return 0;
+  if (!n || !nv) return 0;
+  return maxpy_groups(c, n, d_x, nv, h_alpha, h_dy, NULL);
+}
+
+/* VecMAXPY with the by-product sum x_new^2 in a ticket (the local sum: ranks combine it as they do for phip_vec_reduce_begin) */
+extern "C" int phip_vec_maxpy_reduce(phip_ctx c, int32_t n, double *d_x, int32_t nv, const double *h_alpha, const double *const *h_dy, int publish, phip_ticket *t)
+{
+  CHECK_CTX(c, "phip_vec_maxpy_reduce"); CHECK_N(n, "phip_vec_maxpy_reduce");
+  PHIP_REQUIRE(nv >= 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_maxpy_reduce: nv=%d (at least one vector)", nv);
+  PHIP_REQUIRE(h_alpha && h_dy, PHIP_ERR_ARG_NULL, "phip_vec_maxpy_reduce: null argument");
+  PHIP_REQUIRE(t, PHIP_ERR_ARG_NULL, "phip_vec_maxpy_reduce: null ticket");
+  RedCtl ctl;
+  int    rc = phip_ticket_open(c, 1, publish, t, &ctl);
+  if (rc) return rc;
+  return maxpy_groups(c, n, d_x, nv, h_alpha, h_dy, &ctl); /* n = 0 included: one workgroup publishes the zero sum */
 }
 
 /* ---- the entry point that allocates nothing (include/petschip.h: phip_vec_mdot_static) -------------------------------------------

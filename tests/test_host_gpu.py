@@ -793,6 +793,11 @@ def test_byproduct_cache(orc, size):
             out["zy2", on] = z.dot(y)
             z.axpy(1.0, y)
             out["nz2", on] = z.norm()
+            # VecMAXPY leaves sum z^2 behind (the VecNormalize after the GMRES orthogonalisation); a later write invalidates it
+            z.maxpy([0.5, -0.25], [x, y])
+            out["nz3", on] = z.norm()
+            out["nz3n", on] = z.normalize()
+            out["nz4", on] = z.norm()
         comm.set_byproducts(True)
         for o in (x, y, z, d, A):
             o.destroy()
@@ -803,7 +808,8 @@ def test_byproduct_cache(orc, size):
     dg = np.linspace(0.5, 1.5, N)
     zo = yo * dg
     ref = {"xy": xg @ yo, "yx": xg @ yo, "nz": np.linalg.norm(zo), "zy": zo @ yo, "dz": dg @ zo, "xy2": 2 * (xg @ yo), "zy2": 2 * (zo @ yo),
-           "nz2": np.linalg.norm(zo + 2 * yo)}
+           "nz2": np.linalg.norm(zo + 2 * yo), "nz3": np.linalg.norm(zo + 2 * yo + 0.5 * xg - 0.5 * yo),
+           "nz3n": np.linalg.norm(zo + 2 * yo + 0.5 * xg - 0.5 * yo), "nz4": 1.0}
     for key, val in ref.items():
         for on in (True, False):
             assert abs(res[key, on] - val) <= 1e-12 * max(abs(val), 1.0), (key, on, res[key, on], val)

@@ -69,6 +69,51 @@ def test_ring_processes_shm(n):
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("phip_")]  # the segment's name is gone after the first round
 
 
+def test_ring_ignores_stale_segment():
+    """A run that died during set-up leaves /dev/shm/phip_<hash> behind, ready-marked and with old sequence words.  A later run under
+    the same key must not take it: ranks other than 0 accept a segment only while its creator is alive."""
+    import struct
+    n = 2
+    key = os.urandom(128)
+    h = 1469598103934665603
+    for b in key:
+        h = ((h ^ b) * 1099511628211) & (2**64 - 1)
+    h = ((h ^ n) * 1099511628211) & (2**64 - 1)
+    name = "/dev/shm/phip_%016x" % h
+    dead = subprocess.Popen([sys.executable, "-c", "pass"])
+    dead.wait()
+    slot = 64 + 8 * 128
+    seg = bytearray(64 + slot * 4 * n)
+    struct.pack_into("<QQ", seg, 0, 0x70686970686f7374, dead.pid)
+    for k in range(4 * n):
+        struct.pack_into("<Q", seg, 64 + slot * k, 1)       # "round 1 already written" by everyone, with garbage payloads
+        seg[64 + slot * k + 64:64 + slot * k + 72] = b"\xff" * 8
+    with open(name, "wb") as f:
+        f.write(seg)
+    try:
+        env = dict(os.environ, PHIP_HOST_RING_TIMEOUT="30")
+        # rank 1 first, so that it meets the leftover before rank 0 replaces it
+        p1 = subprocess.Popen([sys.executable, os.path.join(HERE, "_ring_worker.py"), key.hex(), str(n), "1", "50"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        import time
+        time.sleep(1.0)
+        p0 = subprocess.Popen([sys.executable, os.path.join(HERE, "_ring_worker.py"), key.hex(), str(n), "0", "50"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        outs = []
+        for p in (p0, p1):
+            try:
+                o, _ = p.communicate(timeout=90)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                o, _ = p.communicate()
+            outs.append(o)
+        for r, (p, o) in enumerate(zip((p0, p1), outs)):
+            assert p.returncode == 0 and "ring ok rank %d" % r in o, o
+    finally:
+        if os.path.exists(name):
+            os.unlink(name)
+
+
 def test_ring_missing_peer_times_out():
     """A rank whose peers never arrive gets an error, not a hang."""
     from petsc_amd import capi

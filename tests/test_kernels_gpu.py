@@ -865,6 +865,29 @@ def test_byproduct_tickets(ctx, orc):
             for p in (dx, dv, dy):
                 ctx.free(p)
             ctx.check(L.phip_mat_destroy(A))
+    # x += sum a_k y_k with {sum x_new^2}: same x bits as phip_vec_maxpy, every instantiation and the split above 16 vectors
+    for n, nv in [(0, 1), (1, 1), (7, 3), (1000, 2), (1001, 16), (300001, 5), (300001, 31), (2097153, 17)]:
+        x0 = rng.standard_normal(n)
+        ys = [rng.standard_normal(n) for _ in range(nv)]
+        al = rng.standard_normal(nv)
+        dys = [ctx.to_device(y if n else np.zeros(1)) for y in ys]
+        arr = (C.c_void_p * nv)(*dys)
+        alp = al.ctypes.data_as(C.POINTER(C.c_double))
+        dx1, dx2 = ctx.to_device(x0 if n else np.zeros(1)), ctx.to_device(x0 if n else np.zeros(1))
+        ctx.check(L.phip_vec_maxpy(ctx.h, n, dx1, nv, alp, arr))
+        t = Ticket()
+        ctx.check(L.phip_vec_maxpy_reduce(ctx.h, n, dx2, nv, alp, arr, 1, C.byref(t)))
+        val = np.zeros(1)
+        ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t), val.ctypes.data_as(C.POINTER(C.c_double))))
+        x1 = ctx.to_host(dx1, n)
+        np.testing.assert_array_equal(ctx.to_host(dx2, n), x1)
+        if n:
+            assert np.abs(x1 - orc.maxpy(x0, al, ys)).max() <= 1e-13 * (1 + np.abs(al).sum() * 6)
+        assert abs(val[0] - x1 @ x1) <= 1e-13 * max(1.0, x1 @ x1), (n, nv)
+        for p_ in dys + [dx1, dx2]:
+            ctx.free(p_)
+    t = Ticket()
+    assert L.phip_vec_maxpy_reduce(ctx.h, 8, None, 0, None, None, 1, C.byref(t)) != 0   # needs at least one vector
     # a ticket expires after 63 newer ones
     dx = ctx.to_device(np.ones(8)); dw = ctx.to_device(np.zeros(8))
     dy = ctx.to_device(np.full(8, 2.0))
