@@ -141,7 +141,7 @@ def layout_of(L, hA, m, n, nz):
         real = 12 * nz + 4 * (m + 1) + 8 * n + 8 * m + 5 * nb.value + (20 * n if hu_.value else 0)
         return "spmv_rowblock_kernel", "CSR row blocks (12 B/nz)" + (", x gathered in hot-column order (+20 B/column)" if hu_.value else ""), real, alg
     if dmu_.value:
-        return ("spmv_dmask_kernel", "diagonal masks: %d (diagonal, value) pairs, a 32-bit set of them per row (4 B/row)" % dmn_.value,
+        return ("spmv_dmask4_kernel", "diagonal masks: %d (diagonal, value) pairs, a 32-bit set of them per row (4 B/row), four rows a lane" % dmn_.value,
                 4 * 512 * nsl + 8 * n + 8 * m, alg)
     if vdu_.value:
         return ("spmv_pair_kernel", "SELL-dict with a pair dictionary of %d (diagonal, value) pairs (1 B/nz)" % vdn_.value,
@@ -178,7 +178,7 @@ def roofline_obj(workload, kernel, layout, real_bytes, alg_bytes, avg_us, pcts, 
     return o
 
 
-def vec_kernels(L, ctx, tm, m):
+def vec_kernels(L, ctx, tm, m, workload=""):
     """the two vector launches of a KSPCG iteration (cg.c:222-229 batch with its three fused sums; VecAYPX cg.c:202), back to back"""
     from petsc_amd.capi import Context, Ticket
     dev = Context.__new__(Context)
@@ -201,7 +201,7 @@ def vec_kernels(L, ctx, tm, m):
     for name, kern, fn, nbytes, what in (("cg_batch", "cg_update_kernel", cg_batch, 64 * m, "VecAXPY(X,a,P) + VecAXPY(R,-a,W) + VecPointwiseMult(Z,D,R) with 3 fused sums, one launch: 5 vectors read, 3 written"),
                                          ("aypx", "ew_kernel<AYPX>", aypx, 24 * m, "VecAYPX(P,b,Z): 2 vectors read, 1 written")):
         avg, pcts = tm.kernel(fn, REPS, 10)
-        out[name] = roofline_obj("", kern, "contiguous double[m]", nbytes, nbytes, avg, pcts, resident_bytes=nbytes, extra={"what": what})
+        out[name] = roofline_obj(workload, kern, "contiguous double[m]", nbytes, nbytes, avg, pcts, resident_bytes=nbytes, extra={"what": what})
     for v in vecs:
         dev.free(v)
     return out
@@ -379,7 +379,7 @@ def main():
         lv.free(dl)
     y2.destroy()
     x.set_array(xsave)
-    vk = vec_kernels(L, comm.ctx, tm, m)
+    vk = vec_kernels(L, comm.ctx, tm, m, a.workload if world == 1 else "")
 
     tot = np.array([float(iter_bytes), float(spmv_bytes + spmv_add_bytes), float(dt), float(spmv_ms), float(b2b_us), float(mm_us), float(m), float(nz_local)])
     if dist is not None:
