@@ -141,6 +141,10 @@ def layout_of(L, hA, m, n, nz):
         real = 12 * nz + 4 * (m + 1) + 8 * n + 8 * m + 5 * nb.value + (20 * n if hu_.value else 0)
         return "spmv_rowblock_kernel", "CSR row blocks (12 B/nz)" + (", x gathered in hot-column order (+20 B/column)" if hu_.value else ""), real, alg
     if dmu_.value:
+        if m >= (4 << 20):  # the library's size rule (phip_set_dmask_kernel)
+            nwaves = 4 * ((m + 1023) // 1024)
+            return ("spmv_dmaskg_kernel", "diagonal masks: %d (diagonal, value) pairs in 64-byte group descriptors; per wave of 256 rows and pair four 64-bit lane masks (33 x 32 B per wave), four rows a lane" % dmn_.value,
+                    33 * 32 * nwaves + 8 * n + 8 * m, alg)
         return ("spmv_dmask4_kernel", "diagonal masks: %d (diagonal, value) pairs, a 32-bit set of them per row (4 B/row), four rows a lane" % dmn_.value,
                 4 * 512 * nsl + 8 * n + 8 * m, alg)
     if vdu_.value:

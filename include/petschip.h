@@ -62,6 +62,7 @@ typedef struct phip_halo_s *phip_halo;
 int         phip_init(int device, phip_ctx *ctx);
 int         phip_finalize(phip_ctx ctx);
 const char *phip_last_error(void);
+int         phip_device_count(int *count); /* GPUs this process can see (hipGetDeviceCount; 0 when there is no usable driver); needs no context */
 int         phip_device_info(phip_ctx ctx, int *device, int *cu_count, size_t *hbm_bytes, char *name, int name_len);
 int         phip_malloc(phip_ctx ctx, size_t bytes, void **d_ptr);
 int         phip_free(phip_ctx ctx, void *d_ptr);
@@ -158,6 +159,10 @@ int phip_mat_value_dict_info(phip_mat A, int *built, int *in_use, int32_t *npair
  * that sums one partial per slice; smaller matrices keep the single-launch pair-code kernel there); 2: for every product.
  * phip_mat_set_diag_mask switches a built layout off (back to the pair codes) and on. */
 int phip_set_default_diag_mask(int mode);
+/* which of the two diagonal-mask kernels runs (same bits): 0 (default) by size -- spmv_dmaskg_kernel (group descriptors and transposed
+ * masks read by the scalar unit, the masks as execution masks) from 4 Mi rows on, spmv_dmask4_kernel (a bit set per row) below --
+ * 4 / 5: that kernel for every size.  PHIP_DMASK_KERNEL sets the initial value. */
+int phip_set_dmask_kernel(int kind);
 int phip_mat_set_diag_mask(phip_mat A, int on);
 int phip_mat_diag_mask_info(phip_mat A, int *built, int *in_use, int32_t *npairs);
 /* tuning: SELL-dict kernel gathers x from LDS-staged contiguous segments (one per cluster of nearby diagonals) instead of through

@@ -16,6 +16,7 @@ SIGNATURES = [
     ("phip_init", C.c_int, [C.c_int, C.POINTER(_vp)]),
     ("phip_finalize", C.c_int, [_vp]),
     ("phip_last_error", C.c_char_p, []),
+    ("phip_device_count", C.c_int, [C.POINTER(C.c_int)]),
     ("phip_device_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.c_char_p, C.c_int]),
     ("phip_malloc", C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     ("phip_free", C.c_int, [_vp, _vp]),
@@ -66,6 +67,7 @@ SIGNATURES = [
     ("phip_mat_set_hot_columns", C.c_int, [_vp, C.c_int]),
     ("phip_mat_hot_columns_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pD, _pD]),
     ("phip_set_default_lds_hot", C.c_int, [C.c_int]),
+    ("phip_set_dmask_kernel", C.c_int, [C.c_int]),
     ("phip_mat_set_lds_hot", C.c_int, [_vp, C.c_int]),
     ("phip_mat_lds_hot_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pI, _pD]),
     ("phip_vec_dot", C.c_int, [_vp, C.c_int32, _vp, _vp, _pD]),

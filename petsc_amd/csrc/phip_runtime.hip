@@ -95,6 +95,15 @@ extern "C" int phip_finalize(phip_ctx c)
   return 0;
 }
 
+extern "C" int phip_device_count(int *count)
+{
+  PHIP_REQUIRE(count, PHIP_ERR_ARG_NULL, "phip_device_count: null argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { n = 0; (void)hipGetLastError(); }
+  *count = n;
+  return 0;
+}
+
 extern "C" int phip_device_info(phip_ctx c, int *device, int *cu_count, size_t *hbm_bytes, char *name, int name_len)
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_device_info: null context");

@@ -90,6 +90,10 @@ struct phip_mat_s {
   int       dm_built, dm_on;
   int32_t   dm_npairs;
   uint32_t *d_rmask;  /* [S * 512] bit q of rmask[r]: row r holds pair q */
+  unsigned long long *d_tmask; /* the same bits transposed (spmv_dmaskg_kernel): [wave of 256 rows][pair q, 33 entries][i] bit l: row 256 wave + 4 l + i holds pair q */
+  int       dm_dmin, dm_dmax; /* smallest / largest diagonal of the pair table */
+  void     *d_gdesc;  /* [dm_ndesc + 3] DmGroup: the groups of spmv_dmaskg_kernel (at most one pair per place of the window) */
+  int       dm_ndesc;
   double   *d_dotpart; /* [4 S] the fused dot's partial sum of each wave (spmv_dmask_kernel<DOT>, summed by dot_wave_partials_kernel) */
   int32_t  *d_dmoffs; /* [32] */
   double   *d_dmvals; /* [32] */
@@ -692,6 +696,135 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmask4_kernel(int32_t m, in
   }
 }
 
+struct alignas(32) DmWords { unsigned long long w[4]; };
+/* a group: base diagonal D, span (1 .. DM4_SPAN diagonals), and for each place j of the window the pair on diagonal D + j: its index
+   (DMASK_MAX_PAIRS: none) and its value */
+struct alignas(64) DmGroup { int32_t D, span; int32_t q[DM4_SPAN]; int32_t pad1[3]; double v[DM4_SPAN]; int32_t pad2[2]; };
+static_assert(sizeof(DmGroup) == 64, "one group descriptor = one s_load_dwordx16");
+typedef uint32_t phip_u32x16 __attribute__((ext_vector_type(16)));
+#define DMG_WAVE_ROWS 256               /* rows of a wave: lane l holds the rows 4 l .. 4 l + 3 of them */
+#define DMG_WG_ROWS (DMG_WAVE_ROWS * (PHIP_THREADS / 64))
+#define DMG_WORDS (DMASK_MAX_PAIRS + 1) /* mask entries of a wave: one per pair and an empty one */
+
+/* s[i] += v * w[i + OFF] for the rows i whose lanes the words select.  The four products are formed in all lanes; each sum is then taken
+   with the word as the execution mask, set by the scalar unit -- no test, no select, no branch: two vector instructions a row.  The
+   wave is fully active here (uniform control flow, workgroups of 256), so the mask is restored to all ones. */
+template <int OFF>
+__device__ __forceinline__ void dmg_step(double (&s)[4], const double (&w)[DM4_WIN], double v, const DmWords &mw)
+{
+  double t0, t1, t2, t3;
+  asm volatile("v_mul_f64 %[t0], %[v], %[w0]\n\t"
+               "v_mul_f64 %[t1], %[v], %[w1]\n\t"
+               "v_mul_f64 %[t2], %[v], %[w2]\n\t"
+               "v_mul_f64 %[t3], %[v], %[w3]\n\t"
+               "s_mov_b64 exec, %[m0]\n\t"
+               "v_add_f64 %[s0], %[s0], %[t0]\n\t"
+               "s_mov_b64 exec, %[m1]\n\t"
+               "v_add_f64 %[s1], %[s1], %[t1]\n\t"
+               "s_mov_b64 exec, %[m2]\n\t"
+               "v_add_f64 %[s2], %[s2], %[t2]\n\t"
+               "s_mov_b64 exec, %[m3]\n\t"
+               "v_add_f64 %[s3], %[s3], %[t3]\n\t"
+               "s_mov_b64 exec, -1"
+               : [s0] "+v"(s[0]), [s1] "+v"(s[1]), [s2] "+v"(s[2]), [s3] "+v"(s[3]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+               : [v] "s"(v), [w0] "v"(w[OFF]), [w1] "v"(w[OFF + 1]), [w2] "v"(w[OFF + 2]), [w3] "v"(w[OFF + 3]), [m0] "s"(mw.w[0]), [m1] "s"(mw.w[1]),
+                 [m2] "s"(mw.w[2]), [m3] "s"(mw.w[3]));
+}
+
+/* spmv_dmask4_kernel without its scalar overhead.  Its counters show 673 scalar against 389 vector instructions per wave (finding the
+   pairs by walking bit sets, table reads with v_readlane, a three-way dispatch on the pair's place in the window, a test and a select
+   per row and pair): the scalar unit, shared by the four SIMDs of a CU, was busy throughout.  Here a group is one 64-byte descriptor
+   fetched with one scalar load, one group ahead; the places of the window are compile-time; the masks come TRANSPOSED, per wave and
+   pair one 64-bit word for each of the lane's four rows (tmask), fetched by scalar loads and used as execution masks; a pair every
+   row holds runs through the same code with full words.  27-point 256^3: 116 -> 91 us; what is left is the vector L1 (one access a
+   clock for the whole launch, TCP_TOTAL_CACHE_ACCESSES) with the waves waiting on it two thirds of their time.  Tried on top of this
+   and slower, all bit-exact: two windows in flight (97 us), contiguous lanes with pairs of rows (91 us), the upper half of the window
+   from the next lane through the lane-shift network with aligned loads, 252 or 248 rows a wave (106 / 112 us: fewer L1 accesses,
+   but 65 % more L2 misses).  The same sums in the same order as spmv_dmask4_kernel: the same bits.
+   dmin / dmax: smallest and largest diagonal of the table: a wave all of whose windows stay inside x (all but the first and last few)
+   takes the loop without range tests. */
+template <bool DOT, bool ADD>
+__global__ __launch_bounds__(PHIP_THREADS) void spmv_dmaskg_kernel(int32_t m, int32_t n, const DmWords *__restrict__ tmask, const phip_u32x16 *__restrict__ gdesc,
+                                                                   int ngroups, int dmin, int dmax, const double *__restrict__ x, const double *__restrict__ yin,
+                                                                   double *__restrict__ yout, const double *__restrict__ dotv, double *__restrict__ wavepart, int nty)
+{
+#pragma clang fp contract(off)
+  const int      t = threadIdx.x;
+  const int      wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (PHIP_THREADS / 64) + (t >> 6));
+  const int64_t  w0 = (int64_t)wave * DMG_WAVE_ROWS; /* first row of this wave */
+  const int      r0 = (int)blockIdx.x * DMG_WG_ROWS + DM4_ROWS * t;
+  const int      nact = m - r0; /* rows r0 .. r0 + 3 exist while i < nact */
+  double         y0[DM4_ROWS] = {0.0, 0.0, 0.0, 0.0}, s[DM4_ROWS];
+  if (ADD) {
+    if (nact >= DM4_ROWS) {
+      const phip_v2d_u a = *reinterpret_cast<const phip_v2d_u *>(yin + r0), b = *reinterpret_cast<const phip_v2d_u *>(yin + r0 + 2);
+      y0[0] = a.x; y0[1] = a.y; y0[2] = b.x; y0[3] = b.y;
+    } else {
+#pragma unroll
+      for (int i = 0; i < DM4_ROWS; i++) if (i < nact) y0[i] = yin[r0 + i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DM4_ROWS; i++) s[i] = y0[i];
+  const DmWords *tmw = tmask + (size_t)wave * DMG_WORDS;
+  auto run = [&](auto fastc) {
+    constexpr bool FAST = decltype(fastc)::value;
+    DmGroup nxt = __builtin_bit_cast(DmGroup, gdesc[0]);
+    for (int g = 0; g < ngroups; g++) {
+      const DmGroup d = nxt;
+      nxt = __builtin_bit_cast(DmGroup, gdesc[g + 1]); /* the table has a spare descriptor behind the last group */
+      double w[DM4_WIN] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      if (FAST) { /* no range tests */
+        const double    *p = x + ((int64_t)r0 + d.D);
+        const phip_v2d_u a = *reinterpret_cast<const phip_v2d_u *>(p), b = *reinterpret_cast<const phip_v2d_u *>(p + 2);
+        w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
+        if (d.span > 1) { const phip_v2d_u c = *reinterpret_cast<const phip_v2d_u *>(p + 4); w[4] = c.x; w[5] = c.y; }
+      } else { /* entry by entry with clamped indices (an entry outside the row's own pairs is never used) */
+#pragma unroll
+        for (int j = 0; j < DM4_WIN; j++) {
+          int64_t k = (int64_t)r0 + d.D + j;
+          k = k < 0 ? 0 : (k >= (int64_t)n ? (int64_t)n - 1 : k);
+          w[j] = x[k];
+        }
+      }
+      /* the mask words, requested right behind the window and held here (the empty statement "uses" them): left to itself the compiler
+         moves each request to its use, where the wave would sit out the latency alone */
+      const DmWords m0 = tmw[d.q[0]], m1 = tmw[d.q[1]], m2 = tmw[d.q[2]];
+      asm volatile("" ::"s"(m0.w[0]), "s"(m0.w[1]), "s"(m0.w[2]), "s"(m0.w[3]), "s"(m1.w[0]), "s"(m1.w[1]), "s"(m1.w[2]), "s"(m1.w[3]));
+      asm volatile("" ::"s"(m2.w[0]), "s"(m2.w[1]), "s"(m2.w[2]), "s"(m2.w[3]));
+      dmg_step<0>(s, w, d.v[0], m0); /* the first place of a group always carries a pair */
+      if (d.span > 1) {
+        dmg_step<1>(s, w, d.v[1], m1); /* a place without a pair: the empty words, nothing is added */
+        dmg_step<2>(s, w, d.v[2], m2);
+      }
+    }
+  };
+  if (w0 + dmin >= 0 && w0 + DMG_WAVE_ROWS - 1 + dmax + (DM4_SPAN - 1) < (int64_t)n) run(std::true_type());
+  else run(std::false_type());
+  if (nact >= DM4_ROWS) {
+    st_result2(yout + r0, s[0], s[1], nty);
+    st_result2(yout + r0 + 2, s[2], s[3], nty);
+  } else {
+#pragma unroll
+    for (int i = 0; i < DM4_ROWS; i++) if (i < nact) yout[r0 + i] = s[i];
+  }
+  if (DOT) { /* one partial per wave, stored and forgotten (dot_wave_partials_kernel sums them); the weights are requested only now */
+    double dv[DM4_ROWS] = {0.0, 0.0, 0.0, 0.0};
+    if (nact >= DM4_ROWS) {
+      const phip_v2d_u a = *reinterpret_cast<const phip_v2d_u *>(dotv + r0), b = *reinterpret_cast<const phip_v2d_u *>(dotv + r0 + 2);
+      dv[0] = a.x; dv[1] = a.y; dv[2] = b.x; dv[3] = b.y;
+    } else {
+#pragma unroll
+      for (int i = 0; i < DM4_ROWS; i++) if (i < nact) dv[i] = dotv[r0 + i];
+    }
+    double dacc = 0.0;
+#pragma unroll
+    for (int i = 0; i < DM4_ROWS; i++) if (i < nact) dacc += dv[i] * (ADD ? s[i] - y0[i] : s[i]); /* MultAdd: the increment A x, not z */
+    dacc = wave_sum(dacc);
+    if ((t & 63) == 0) wavepart[(size_t)blockIdx.x * (PHIP_THREADS / 64) + (t >> 6)] = dacc;
+  }
+}
+
 /* second half of the fused dot of spmv_dmask_kernel: np wave partials, summed in a fixed order (thread t of workgroup b adds the entries
    (b * 256 + t) + k * gridDim.x * 256, k ascending, sixteen loads in flight; then block_sum and reduce_tail) and delivered as
    reduce_tail delivers */
@@ -1246,7 +1379,8 @@ static void free_pairs(phip_mat A)
 
 static void free_dmask(phip_mat A)
 {
-  if (A->ctx->device >= 0) { hipFree(A->d_rmask); hipFree(A->d_dmoffs); hipFree(A->d_dmvals); hipFree(A->d_dotpart); hipFree(A->d_dmgrp); }
+  if (A->ctx->device >= 0) { hipFree(A->d_rmask); hipFree(A->d_dmoffs); hipFree(A->d_dmvals); hipFree(A->d_dotpart); hipFree(A->d_dmgrp); hipFree(A->d_tmask); hipFree(A->d_gdesc); }
+  A->d_tmask = NULL; A->d_gdesc = NULL; A->dm_ndesc = 0;
   A->d_rmask = NULL; A->d_dmoffs = NULL; A->d_dmvals = NULL; A->d_dotpart = NULL; A->d_dmgrp = NULL; A->dm_ngroups = 0; A->dm_built = 0; A->dm_on = 0; A->dm_npairs = 0;
 }
 
@@ -1254,6 +1388,8 @@ static void free_dmask(phip_mat A)
    when some row does not meet its pairs in strictly ascending diagonal order (unsorted or repeated columns): such a row's k-ascending
    sum is not the ascending-diagonal sum. */
 static int g_dm_mode = -1;
+static int g_dm_kernel = -1; /* 0 by size, 4 spmv_dmask4_kernel, 5 spmv_dmaskg_kernel */
+#define DMG_MIN_ROWS (4 << 20)
 static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std::vector<int32_t> &poffs, const std::vector<double> &pvals, int npairs)
 {
   const int was_on = A->dm_built ? A->dm_on : 1;
@@ -1264,7 +1400,7 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
   std::stable_sort(order, order + npairs, [&](int a, int b) { return poffs[(size_t)a] < poffs[(size_t)b]; });
   for (int q = 0; q < npairs; q++) rank[order[q]] = q;
   const int32_t         S = A->sell_nslices;
-  std::vector<uint32_t> rmask((size_t)S * SELL_H + PHIP_THREADS * DM4_ROWS + 2, 0u); /* padded to whole workgroups of spmv_dmask4_kernel */
+  std::vector<uint32_t> rmask((size_t)S * SELL_H + PHIP_THREADS * 8 + 2, 0u); /* padded to whole workgroups of spmv_dmask4_kernel / spmv_dmaskg_kernel */
   const std::vector<int32_t> &rp = *A->h_rowptr;
   for (int32_t r = 0; r < A->m; r++) {
     const int32_t b = r / SELL_H;
@@ -1296,8 +1432,46 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
     ngroups++;
   }
   A->dm_ngroups = ngroups;
+  /* the descriptors of spmv_dmaskg_kernel: as above, but a place of the window holds at most one pair (a diagonal that carries several
+     values opens a new group for each further one) */
+  DmGroup gd[DMASK_MAX_PAIRS + 4];
+  memset(gd, 0, sizeof(gd));
+  for (auto &G : gd) { G.span = 1; for (int j = 0; j < DM4_SPAN; j++) G.q[j] = DMASK_MAX_PAIRS; }
+  int ndesc = 0;
+  for (int q = 0; q < npairs;) {
+    DmGroup &G = gd[ndesc++];
+    G.D = offs[q];
+    while (q < npairs && (int64_t)offs[q] - G.D < DM4_SPAN && G.q[offs[q] - G.D] == DMASK_MAX_PAIRS) {
+      const int j = offs[q] - G.D;
+      G.q[j] = q; G.v[j] = vals[q]; G.span = j + 1;
+      q++;
+    }
+  }
+  A->dm_dmin = offs[0]; A->dm_dmax = offs[npairs - 1];
+  A->dm_ndesc = ndesc;
+  /* the transposed masks: one wave = 256 rows, lane l holds the rows 4 l .. 4 l + 3 of them (words 0 .. 3); entry DMASK_MAX_PAIRS of
+     a wave stays empty (the places of a window that carry no pair) */
+  const size_t nwaves = (((size_t)A->m + DMG_WG_ROWS - 1) / DMG_WG_ROWS) * (PHIP_THREADS / 64);
+  std::vector<unsigned long long> tmask(std::max<size_t>(nwaves, 1) * DMG_WORDS * 4, 0ull);
+  for (size_t wv = 0; wv < nwaves; wv++) {
+    const int64_t first = (int64_t)wv * DMG_WAVE_ROWS;
+    const int     nrows = (int)std::min<int64_t>(DMG_WAVE_ROWS, std::max<int64_t>((int64_t)A->m - first, 0));
+    uint32_t      any = 0u, all = ~0u;
+    for (int k = 0; k < nrows; k++) { any |= rmask[(size_t)(first + k)]; all &= rmask[(size_t)(first + k)]; }
+    if (!nrows) continue;
+    unsigned long long *tw = tmask.data() + wv * DMG_WORDS * 4;
+    unsigned long long  act[4]; /* the lanes whose row i exists */
+    for (int i = 0; i < 4; i++) { const int nl = (nrows - i + 3) / 4; act[i] = nl >= 64 ? ~0ull : ((1ull << (nl > 0 ? nl : 0)) - 1ull); }
+    for (uint32_t pm = any; pm; pm &= pm - 1) { const int q = __builtin_ctz(pm); for (int i = 0; i < 4; i++) tw[q * 4 + i] = act[i]; } /* start from "all rows" */
+    const uint32_t part = any & ~all;
+    if (!part) continue;
+    for (int k = 0; k < nrows; k++) /* ... and take out the few rows that miss the pair */
+      for (uint32_t miss = part & ~rmask[(size_t)(first + k)]; miss; miss &= miss - 1) tw[__builtin_ctz(miss) * 4 + (k & 3)] &= ~(1ull << (k >> 2));
+  }
   hipStream_t st = A->ctx->stream;
   if (!A->d_rmask) {
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_tmask, sizeof(unsigned long long) * tmask.size()));
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_gdesc, sizeof(gd)));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dmgrp, sizeof(grp)));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rmask, sizeof(uint32_t) * rmask.size()));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dmoffs, sizeof(offs)));
@@ -1305,6 +1479,8 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dotpart, sizeof(double) * ((size_t)S * (PHIP_THREADS / 64) + 2)));
   }
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_rmask, rmask.data(), sizeof(uint32_t) * rmask.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_tmask, tmask.data(), sizeof(unsigned long long) * tmask.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_gdesc, gd, sizeof(gd), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmoffs, offs, sizeof(offs), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmvals, vals, sizeof(vals), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmgrp, grp, sizeof(grp), hipMemcpyHostToDevice, st));
@@ -1609,6 +1785,14 @@ __global__ __launch_bounds__(PHIP_THREADS) void sell_refresh_values_kernel(int32
 }
 
 /* the pair tables after a shift: the pairs on diagonal 0 stand for the diagonal entries */
+/* the group descriptors carry copies of the pair values: bring them in line with the pair table after it changed */
+__global__ void dmask_desc_refresh_kernel(int ndesc, DmGroup *__restrict__ gd, const double *__restrict__ vals)
+{
+  const int g = threadIdx.x / DM4_SPAN, j = threadIdx.x % DM4_SPAN;
+  if (g < ndesc && gd[g].q[j] < DMASK_MAX_PAIRS) gd[g].v[j] = vals[gd[g].q[j]];
+}
+#define DMASK_DESC_REFRESH(A, st) do { if ((A)->dm_built) hipLaunchKernelGGL(dmask_desc_refresh_kernel, dim3(1), dim3(DMASK_MAX_PAIRS * DM4_SPAN), 0, st, (A)->dm_ndesc, reinterpret_cast<DmGroup *>((A)->d_gdesc), (A)->d_dmvals); } while (0)
+
 __global__ void pair_table_shift_kernel(int n, const int32_t *__restrict__ offs, double *__restrict__ vals, double alpha)
 {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1639,6 +1823,7 @@ extern "C" int phip_mat_scale(phip_mat A, double alpha)
   if (A->sell_built) hipLaunchKernelGGL(mat_scale_values_kernel, dim3(dev_grid(A->sell_padded)), dim3(PHIP_THREADS), 0, st, A->sell_padded, A->d_sval, alpha);
   if (A->vd_built) hipLaunchKernelGGL(mat_scale_values_kernel, dim3(1), dim3(PHIP_THREADS), 0, st, (int64_t)SELL_MAX_OFFS, A->d_svtab, alpha);
   if (A->dm_built) hipLaunchKernelGGL(mat_scale_values_kernel, dim3(1), dim3(PHIP_THREADS), 0, st, (int64_t)DMASK_MAX_PAIRS, A->d_dmvals, alpha);
+  DMASK_DESC_REFRESH(A, st);
   PHIP_CHECK_HIP(hipGetLastError());
   return A->T ? phip_mat_scale(A->T, alpha) : 0;
 }
@@ -1653,6 +1838,7 @@ extern "C" int phip_mat_shift(phip_mat A, double alpha)
   if (rc) return rc;
   if (A->vd_built) hipLaunchKernelGGL(pair_table_shift_kernel, dim3(1), dim3(SELL_MAX_OFFS), 0, st, A->vd_npairs, A->d_spoffs, A->d_svtab, alpha);
   if (A->dm_built) hipLaunchKernelGGL(pair_table_shift_kernel, dim3(1), dim3(DMASK_MAX_PAIRS), 0, st, A->dm_npairs, A->d_dmoffs, A->d_dmvals, alpha);
+  DMASK_DESC_REFRESH(A, st);
   PHIP_CHECK_HIP(hipGetLastError());
   return A->T ? phip_mat_shift(A->T, alpha) : 0;
 }
@@ -1680,6 +1866,7 @@ extern "C" int phip_mat_zero_entries(phip_mat A)
   if (A->sell_built) PHIP_CHECK_HIP(hipMemsetAsync(A->d_sval, 0, sizeof(double) * (size_t)A->sell_padded, st));
   if (A->vd_built) PHIP_CHECK_HIP(hipMemsetAsync(A->d_svtab, 0, sizeof(double) * SELL_MAX_OFFS, st));
   if (A->dm_built) PHIP_CHECK_HIP(hipMemsetAsync(A->d_dmvals, 0, sizeof(double) * DMASK_MAX_PAIRS, st));
+  DMASK_DESC_REFRESH(A, st);
   return A->T ? phip_mat_zero_entries(A->T) : 0;
 }
 
@@ -1767,7 +1954,19 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
       static const int dm_rows_env = getenv("PHIP_DMASK_ROWS") ? atoi(getenv("PHIP_DMASK_ROWS")) : 4;
       static const int dm_ug_env = getenv("PHIP_DMASK_GROUPS") ? atoi(getenv("PHIP_DMASK_GROUPS")) : 0;
       int              nwg;
-      if (dm_rows_env != 2) {
+      /* spmv_dmaskg_kernel from 4 Mi rows on, spmv_dmask4_kernel below (27-point 256^3: 116 -> 91 us with the former; 7-point 128^3
+         inside KSPCG 18.2 k it/s with the latter against 17.6 k: its launches are 10 us long and start from cold scalar caches);
+         PHIP_DMASK_KERNEL / phip_set_dmask_kernel: 4 or 5 (the group-descriptor kernel) for all sizes */
+      if (g_dm_kernel < 0) g_dm_kernel = getenv("PHIP_DMASK_KERNEL") ? atoi(getenv("PHIP_DMASK_KERNEL")) : 0;
+      const bool use_g = g_dm_kernel == 5 || (g_dm_kernel != 4 && A->m >= DMG_MIN_ROWS);
+      if (dm_rows_env != 2 && use_g) {
+        nwg = (A->m + DMG_WG_ROWS - 1) / DMG_WG_ROWS;
+#define DMG_LAUNCH(ADDv)                                                                                                                                  \
+  hipLaunchKernelGGL((spmv_dmaskg_kernel<DOT, ADDv>), dim3((unsigned)nwg), dim3(PHIP_THREADS), 0, st, A->m, A->n, reinterpret_cast<const DmWords *>(A->d_tmask), \
+                     reinterpret_cast<const phip_u32x16 *>(A->d_gdesc), A->dm_ndesc, A->dm_dmin, A->dm_dmax, d_x, d_yin, d_yout, d_v, part, nty)
+        if (add) DMG_LAUNCH(true); else DMG_LAUNCH(false);
+#undef DMG_LAUNCH
+      } else if (dm_rows_env != 2) {
         nwg = (A->m + PHIP_THREADS * DM4_ROWS - 1) / (PHIP_THREADS * DM4_ROWS);
         const int ug = dm_ug_env ? dm_ug_env : 1; /* 27-point 256^3: 1 / 2 / 3 / 4 groups in flight 121.6 / 126.6 / 133.0 / 147.3 us: occupancy hides the latency better */
 #define DM4_LAUNCH(ADDv, UGv)                                                                                                                             \
@@ -2083,6 +2282,13 @@ extern "C" int phip_mat_hot_columns_info(phip_mat A, int *built, int *in_use, do
 
 /* hot columns resident in LDS (setup_lds): on = 0 runs the row-block kernel, 1 the wave kernel built at creation (error if none was
    built).  info: built / in use / K / share of the nonzeros whose column is one of the K. */
+extern "C" int phip_set_dmask_kernel(int kind)
+{
+  PHIP_REQUIRE(kind == 0 || kind == 4 || kind == 5, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_dmask_kernel: %d (0 by size, 4 bit sets per row, 5 group descriptors)", kind);
+  g_dm_kernel = kind;
+  return 0;
+}
+
 extern "C" int phip_set_default_lds_hot(int mode)
 {
   PHIP_REQUIRE(mode >= 0 && mode <= 2, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_default_lds_hot: %d (0 never, 1 when it pays, 2 always)", mode);

@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
-"""Average counter value per launch and kernel from gpurun_out/pmc_pair_*/**/*_counter_collection.csv.  python scripts/pmc_summary.py [substring]"""
+"""Per-kernel means of the counters collected by scripts/pmc_spmv.sh.   python scripts/pmc_summary.py <tag> [kernel-substring]"""
 import collections
 import csv
 import glob
 import json
+import os
 import sys
 
-want = sys.argv[1] if len(sys.argv) > 1 else "spmv"
-out = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob("gpurun_out/pmc_pair_*/*/*_counter_collection.csv")):
-    for r in csv.DictReader(open(f)):
+tag = sys.argv[1]
+sub = sys.argv[2] if len(sys.argv) > 2 else "spmv"
+out = collections.defaultdict(dict)
+for d in sorted(glob.glob("gpurun_out/pmc_%s_*/" % tag)):
+    fs = glob.glob(d + "*/*_counter_collection.csv")
+    if not fs:
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         k = r["Kernel_Name"].split("(")[0]
-        if want in k:
-            out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-res = {k: {c: round(sum(v) / len(v), 1) for c, v in d.items()} | {"_launches": max(len(v) for v in d.values())} for k, d in out.items()}
-print(json.dumps(res, indent=1, sort_keys=True))
+        if sub in k:
+            acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), v in acc.items():
+        out[k][c] = round(sum(v) / len(v), 1)
+        out[k]["_launches"] = len(v)
+print(json.dumps(out, indent=1, sort_keys=True))

@@ -1,5 +1,7 @@
-"""Worker of tests/test_host_gpu.py::test_multiprocess_shared_gpu: one PROCESS per rank, all on GPU 0, joined by the "shm" backend
-(shared-memory ring for the host collectives, ghost exchange staged through the host).  argv: key(hex) nranks rank"""
+"""Worker of tests/test_host_gpu.py::test_multiprocess_shared_gpu and ::test_multiprocess_rccl: one PROCESS per rank.  Backend "shm":
+all ranks on GPU 0 (shared-memory ring for the host collectives, ghost exchange staged through the host).  Backend "rccl": one GPU
+per rank, the data path of bench.py --gpus N (grouped ncclSend/ncclRecv ghost exchange, host ring or ncclAllReduce reductions).
+argv: key(hex) nranks rank [backend [device]]"""
 import os
 import sys
 
@@ -10,10 +12,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     key, n, r = bytes.fromhex(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    backend = sys.argv[4] if len(sys.argv) > 4 else "shm"
+    device = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     from petsc_amd import generators as G, petsc as P
     from oracle.oracle import Oracle
     orc = Oracle()
-    comm = P.Comm(device=0, backend="shm", id128=key, nranks=n, rank=r)
+    comm = P.Comm(device=device, backend=backend, id128=key, nranks=n, rank=r)
     ai, aj, aa = G.convdiff3d_7pt(12, 10, 9)
     N = len(ai) - 1
     op = orc.operator(ai, aj, aa, n)

@@ -79,6 +79,53 @@ def test_default_hot_columns_and_nontemporal_csr(ctx):
     ctx.check(L.phip_mat_destroy(A))
 
 
+def test_default_group_descriptor_mask_kernel(ctx):
+    """From 4 Mi rows on the diagonal-mask product runs spmv_dmaskg_kernel (group descriptors, transposed masks as execution masks) by
+    default: 7-point 162^3 (4.25 M rows) against the per-row bit-set kernel forced on the same matrix (array-equal; the fused dot
+    within round-off) and a strided sample of rows computed on the host."""
+    from petsc_amd import generators as G
+    from petsc_amd.capi import Ticket
+    L = ctx.lib
+    nn = 162
+    m = nn ** 3
+    assert m >= (4 << 20)
+    ai, aj, aa = G.stencil_rows_native(7, nn, nn, nn, 0, m)
+    A = ctx.mat_create(m, m, ai, aj, aa)
+    db, du, dn = C.c_int(), C.c_int(), C.c_int32()
+    ctx.check(L.phip_mat_diag_mask_info(A, C.byref(db), C.byref(du), C.byref(dn)))
+    assert (db.value, du.value) == (1, 1) and dn.value <= 32
+    x = np.random.default_rng(8).uniform(-1.0, 1.0, m)
+    y0 = np.random.default_rng(9).uniform(-1.0, 1.0, m)
+    dx, dy, dy0 = ctx.to_device(x), ctx.to_device(np.zeros(m)), ctx.to_device(y0)
+    res = {}
+    for kind in (0, 4, 5):
+        ctx.check(L.phip_set_dmask_kernel(kind))
+        try:
+            ctx.check(L.phip_mat_mult(A, dx, dy))
+            mult = ctx.to_host(dy, m)
+            ctx.check(L.phip_mat_multadd(A, dx, dy0, dy))
+            madd = ctx.to_host(dy, m)
+            tk, val = Ticket(), np.zeros(1)
+            ctx.check(L.phip_mat_mult_dot(A, dx, dy, dx, 1, C.byref(tk)))
+            ctx.check(L.phip_ticket_wait(ctx.h, C.byref(tk), val.ctypes.data_as(C.POINTER(C.c_double))))
+            res[kind] = (mult, madd, ctx.to_host(dy, m), val[0])
+        finally:
+            ctx.check(L.phip_set_dmask_kernel(0))
+    for kind in (4, 5):
+        for k in range(3):
+            assert np.array_equal(res[kind][k], res[0][k]), (kind, k)
+        assert abs(res[kind][3] - res[0][3]) <= 1e-12 * np.abs(x * res[0][0]).sum()
+    rows = np.arange(0, m, 1009)
+    ref = np.array([np.dot(aa[ai[r]:ai[r + 1]], x[aj[ai[r]:ai[r + 1]]]) for r in rows])
+    scale = np.abs(ref).max()
+    assert np.abs(res[0][0][rows] - ref).max() <= 1e-12 * scale
+    assert np.abs(res[0][1][rows] - (ref + y0[rows])).max() <= 1e-12 * (scale + 1.0)
+    assert abs(res[0][3] - x @ res[0][0]) <= 1e-12 * np.abs(x * res[0][0]).sum()
+    for p in (dx, dy, dy0):
+        ctx.free(p)
+    ctx.check(L.phip_mat_destroy(A))
+
+
 def test_default_nontemporal_elementwise(ctx):
     """vectors of 6.5 M entries (52 MB >= 48 MiB): the elementwise kernels, the batch kernel and the KSPCG batch read (and partly store)
     past the caches by default; the same calls with the feature off must give the same bits, and the closed forms on a sample."""

@@ -837,3 +837,40 @@ def test_multiprocess_shared_gpu(n):
         outs.append(o)
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and "mp ok rank %d" % r in o, o[-3000:]
+
+
+@pytest.mark.parametrize("device_allreduce", [False, True])
+def test_multiprocess_rccl(device_allreduce):
+    """The route bench.py --gpus N takes: one process and one GPU per rank, backend "rccl" -- set-up handshake (ncclAllGather, grouped
+    send/recv all-to-all), host-name check and shared-memory ring attach, the grouped ncclSend/ncclRecv ghost exchange forward and in
+    reverse with ADD, reductions through the host ring or (PETSCHIP_DEVICE_ALLREDUCE=1) ncclAllReduce -- against the oracle.
+    Needs two GPUs: skipped on a one-GPU box (RCCL refuses two ranks on one device)."""
+    import subprocess
+    import sys
+    import ctypes as C
+    from petsc_amd import capi, petsc as P
+    ndev = C.c_int()
+    capi.load().phip_device_count(C.byref(ndev))
+    if ndev.value < 2:
+        pytest.skip("needs 2 GPUs (RCCL refuses two ranks on one device); this box has %d" % ndev.value)
+    n = 2
+    key = bytes(P.Comm.unique_id()).hex()
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PHIP_HOST_RING_TIMEOUT="60")
+    if device_allreduce:
+        env["PETSCHIP_DEVICE_ALLREDUCE"] = "1"
+    else:
+        env.pop("PETSCHIP_DEVICE_ALLREDUCE", None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "_gpu_mp_worker.py"), key, str(n), str(r), "rccl", str(r)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(n)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=150)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            o, _ = p.communicate()
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "mp ok rank %d" % r in o, o[-3000:]

@@ -346,6 +346,20 @@ def test_value_pair_dictionary(ctx, orc):
                 assert abs(a[0] - b[0]) <= 1e-13 * np.abs(v * on[2]).sum()
             else:
                 np.testing.assert_array_equal(a, b)
+        # both mask kernels (by default the size decides): bit sets per row, and group descriptors with transposed masks
+        for kind in (4, 5):
+            ctx.check(L.phip_set_dmask_kernel(kind))
+            ctx.check(L.phip_set_default_diag_mask(2))
+            try:
+                onk = products(A, m, x, v, y0)
+            finally:
+                ctx.check(L.phip_set_default_diag_mask(1))
+                ctx.check(L.phip_set_dmask_kernel(0))
+            for k, (a, b) in enumerate(zip(on, onk)):
+                if k == 3:
+                    assert abs(a[0] - b[0]) <= 1e-13 * np.abs(v * on[2]).sum()
+                else:
+                    np.testing.assert_array_equal(a, b)
         ctx.check(L.phip_mat_set_diag_mask(A, 0))
         ctx.check(L.phip_mat_diag_mask_info(A, C.byref(db), C.byref(du), C.byref(dn)))
         assert (db.value, du.value) == (1, 0)
