@@ -440,6 +440,7 @@ extern "C" int phip_comm_allreduce(phip_comm c, double *d_buf, int32_t n, int op
   PHIP_FLUSH(c->ctx);
   PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS && c->backend != BACKEND_SHM, PHIP_ERR_SUP, "phip_comm_allreduce: this backend carries no device traffic");
   if (c->backend == BACKEND_RCCL) {
+    PHIP_CHECK_HIP(hipSetDevice(c->ctx->device)); /* the caller's thread may have another device current (torch, a second context) */
     PHIP_CHECK_NCCL(g_rccl.AllReduce(d_buf, d_buf, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->nccl, c->ctx->stream));
     return 0;
   }
@@ -751,7 +752,12 @@ extern "C" int phip_halo_begin(phip_halo h, const double *d_x_local, double *d_l
   }
   if (c->backend == BACKEND_RCCL) {
     /* the exchange may start once the pack (and everything before it on the compute stream, e.g. the previous
-       product that still reads lvec) has finished */
+       product that still reads lvec) has finished.  Order of the two streams over consecutive products: the pack of product k + 1
+       overwrites d_sendbuf only after phip_halo_end of product k made the compute stream wait for ev_done, i.e. for the sends of
+       product k; the receives of product k + 1 overwrite lvec only after ev_packed of k + 1, recorded behind the off-diagonal
+       product of k on the compute stream.  Neighbours with nothing to exchange are skipped on both sides (the counts of a plan
+       agree pairwise, phip_halo_create's callers build them from one all-to-all), an empty group is legal. */
+    PHIP_CHECK_HIP(hipSetDevice(ctx->device)); /* RCCL launches on the current device: the caller's thread may have another one current */
     PHIP_CHECK_HIP(hipEventRecord(h->ev_packed, ctx->stream));
     PHIP_CHECK_HIP(hipStreamWaitEvent(ctx->comm_stream, h->ev_packed, 0));
     if (h->to_n || h->from_n) {
@@ -833,6 +839,7 @@ extern "C" int phip_halo_reverse_begin(phip_halo h, const double *d_lvec)
   if (c->backend == BACKEND_RCCL) {
     /* lvec is complete once everything queued on the compute stream so far has run; the receive buffer is the forward send buffer
        (one scatter context carries one exchange at a time, vscat.c:1670) */
+    PHIP_CHECK_HIP(hipSetDevice(ctx->device));
     PHIP_CHECK_HIP(hipEventRecord(h->ev_packed, ctx->stream));
     PHIP_CHECK_HIP(hipStreamWaitEvent(ctx->comm_stream, h->ev_packed, 0));
     if (h->to_n || h->from_n) {

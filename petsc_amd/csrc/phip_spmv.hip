@@ -35,6 +35,9 @@
 #include "phip_reduce.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #define SPMV_CAP 2046          /* nonzeros per row block; +2 alignment slack = 2048 LDS doubles = 16 KiB */
@@ -48,6 +51,47 @@
 #define SELL_STAGE_MAX_BYTES (64 * 1024)
 
 static int g_default_fmt = 0; /* phip_set_default_mat_format */
+/* The host passes of phip_mat_create (SELL-dict arrays, pair codes, masks) are independent per slice of rows: they run on
+   PHIP_SETUP_THREADS threads (default: the machine's, at most 16) over contiguous chunks in ascending order, so that tables numbered by
+   first appearance come out as in one pass -- the layout does not depend on the number of threads. */
+static int g_setup_threads = 0; /* phip_set_setup_threads; 0: PHIP_SETUP_THREADS or the machine's, at most 16 */
+static int setup_threads(int64_t work)
+{
+  static const int T = [] {
+    int t = getenv("PHIP_SETUP_THREADS") ? atoi(getenv("PHIP_SETUP_THREADS")) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    return t < 1 ? 1 : (t > 64 ? 64 : t);
+  }();
+  return work < (1 << 20) ? 1 : (g_setup_threads > 0 ? g_setup_threads : T);
+}
+template <class F>
+static void par_chunks(int64_t n, int T, F fn) /* fn(chunk, begin, end) */
+{
+  if (T <= 1 || n <= 0) { fn(0, (int64_t)0, n); return; }
+  const int64_t            per = (n + T - 1) / T;
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; t++) {
+    const int64_t b = std::min<int64_t>(n, per * t), e = std::min<int64_t>(n, per * (t + 1));
+    th.emplace_back([&fn, t, b, e] { fn(t, b, e); });
+  }
+  fn(0, (int64_t)0, std::min<int64_t>(n, per));
+  for (auto &x : th) x.join();
+}
+/* a vector of doubles that is not zero-filled when it is sized (the 3.6 GB of padded values of a 27-point 256^3 matrix would be
+   touched once by one thread before the threads fill them) */
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+  template <class U, class... Args> void construct(U *p, Args &&...args) { ::new ((void *)p) U(std::forward<Args>(args)...); }
+  template <class U> void construct(U *p) { ::new ((void *)p) U; }
+};
+typedef std::vector<double, NoInitAlloc<double>> raw_dvec;
+
+/* PHIP_SETUP_TIMING=1: phip_mat_create reports where its time goes (stderr) */
+struct SetupClock {
+  bool on; std::chrono::steady_clock::time_point t;
+  SetupClock() : on(getenv("PHIP_SETUP_TIMING") && atoi(getenv("PHIP_SETUP_TIMING"))), t(std::chrono::steady_clock::now()) {}
+  void lap(const char *what) { if (!on) return; const auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[phip setup] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count()); t = n; }
+};
 static int g_hot_mode = -1;   /* phip_set_default_hot_columns; -1: take PHIP_HOT_COLUMNS or 1 at the first matrix */
 
 struct phip_mat_s {
@@ -1259,68 +1303,123 @@ static void build_plan(const std::vector<int32_t> &rp, int32_t R, int32_t tpr_us
 /* ---- host: SELL-dict layout --------------------------------------------------------------------- */
 /* Decide eligibility and build sval/scode/slen/sptr/soffs from the host CSR.  Returns 1 when built, 0 when not eligible. */
 static int build_sell(const std::vector<int32_t> &rp, int32_t m, int32_t n, const int32_t *cj, const double *ca, std::vector<int64_t> &sptr,
-                      std::vector<uint8_t> &slen, std::vector<int32_t> &soffs, std::vector<double> *sval, std::vector<uint8_t> &scode)
+                      std::vector<uint8_t> &slen, std::vector<int32_t> &soffs, raw_dvec *sval, std::vector<uint8_t> &scode)
 {
   if (m <= 0 || n <= 0) return 0;
   const int64_t nnz = rp[(size_t)m];
   if (nnz == 0) return 0;
   const int32_t S = (m + SELL_H - 1) / SELL_H;
+  const int     T = setup_threads(nnz);
   sptr.assign((size_t)S + 1, 0);
   slen.assign((size_t)S * SELL_H + 2, 0);
-  for (int32_t b = 0; b < S; b++) {
-    int L = 0;
-    for (int32_t r = b * SELL_H; r < m && r < (b + 1) * SELL_H; r++) {
-      const int len = rp[(size_t)r + 1] - rp[(size_t)r];
-      if (len > 255) return 0;
-      slen[(size_t)r] = (uint8_t)len;
-      if (len > L) L = len;
+  std::atomic<int> bad(0);
+  par_chunks(S, T, [&](int, int64_t b0, int64_t b1) {
+    for (int64_t b = b0; b < b1; b++) {
+      int L = 0;
+      for (int64_t r = b * SELL_H; r < m && r < (b + 1) * SELL_H; r++) {
+        const int len = rp[(size_t)r + 1] - rp[(size_t)r];
+        if (len > 255) { bad = 1; return; }
+        slen[(size_t)r] = (uint8_t)len;
+        if (len > L) L = len;
+      }
+      sptr[(size_t)b + 1] = (int64_t)L * SELL_H;
     }
-    sptr[(size_t)b + 1] = sptr[(size_t)b] + (int64_t)L * SELL_H;
-  }
+  });
+  if (bad) return 0;
+  for (int32_t b = 0; b < S; b++) sptr[(size_t)b + 1] += sptr[(size_t)b];
   const int64_t P = sptr[(size_t)S];
   if ((double)P > SELL_MAX_PAD * (double)nnz + SELL_H * 8) return 0;
-  scode.assign((size_t)P + 16, 0);
-  if (sval) sval->assign((size_t)P + 16, 0.0);
-  soffs.clear();
-  uint8_t guess[256];
-  memset(guess, 0, sizeof(guess));
-  for (int32_t b = 0; b < S; b++) {
-    for (int32_t r = b * SELL_H; r < m && r < (b + 1) * SELL_H; r++) {
+  /* the diagonals, numbered by first appearance in row order: every chunk lists its own in that order, the lists are merged in
+     chunk order */
+  std::vector<std::vector<int32_t>> local((size_t)T);
+  par_chunks(S, T, [&](int c, int64_t b0, int64_t b1) {
+    std::vector<int32_t> &mine = local[(size_t)c];
+    uint8_t               guess[256];
+    memset(guess, 0, sizeof(guess));
+    for (int64_t r = b0 * SELL_H; r < m && r < b1 * SELL_H; r++) {
       const int32_t k0 = rp[(size_t)r];
       const int     len = rp[(size_t)r + 1] - k0;
-      const int64_t pos0 = sptr[(size_t)b] + (r - b * SELL_H);
       for (int sl = 0; sl < len; sl++) {
-        const int32_t d = cj[k0 + sl] - r;
-        int           code = guess[sl];
-        if (code >= (int)soffs.size() || soffs[(size_t)code] != d) {
-          code = -1;
-          for (size_t q = 0; q < soffs.size(); q++) if (soffs[q] == d) { code = (int)q; break; }
-          if (code < 0) {
-            if (soffs.size() >= SELL_MAX_OFFS) return 0;
-            code = (int)soffs.size();
-            soffs.push_back(d);
-          }
-          guess[sl] = (uint8_t)code;
+        const int32_t d = cj[k0 + sl] - (int32_t)r;
+        const int     gcode = guess[sl];
+        if (gcode < (int)mine.size() && mine[(size_t)gcode] == d) continue;
+        int code = -1;
+        for (size_t q = 0; q < mine.size(); q++) if (mine[q] == d) { code = (int)q; break; }
+        if (code < 0) {
+          if (mine.size() >= SELL_MAX_OFFS) { bad = 1; return; }
+          code = (int)mine.size();
+          mine.push_back(d);
         }
-        scode[(size_t)(pos0 + (int64_t)sl * SELL_H)] = (uint8_t)code;
-        if (sval) (*sval)[(size_t)(pos0 + (int64_t)sl * SELL_H)] = ca[k0 + sl];
+        guess[sl] = (uint8_t)code;
       }
     }
-  }
+  });
+  if (bad) return 0;
+  soffs.clear();
+  for (const auto &mine : local)
+    for (int32_t d : mine) {
+      bool have = false;
+      for (int32_t e : soffs) if (e == d) { have = true; break; }
+      if (!have) { if (soffs.size() >= SELL_MAX_OFFS) return 0; soffs.push_back(d); }
+    }
+  scode.resize((size_t)P + 16);
+  if (sval) sval->resize((size_t)P + 16);
+  par_chunks(S, T, [&](int, int64_t b0, int64_t b1) {
+    uint8_t guess[256];
+    memset(guess, 0, sizeof(guess));
+    for (int64_t b = b0; b < b1; b++) {
+      const int64_t base = sptr[(size_t)b];
+      const int     L = (int)((sptr[(size_t)b + 1] - base) / SELL_H);
+      for (int64_t r = b * SELL_H; r < (b + 1) * SELL_H; r++) {
+        const int64_t pos0 = base + (r - b * SELL_H);
+        int           len = 0;
+        if (r < m) {
+          const int32_t k0 = rp[(size_t)r];
+          len = rp[(size_t)r + 1] - k0;
+          for (int sl = 0; sl < len; sl++) {
+            const int32_t d = cj[k0 + sl] - (int32_t)r;
+            int           code = guess[sl];
+            if (code >= (int)soffs.size() || soffs[(size_t)code] != d) {
+              for (size_t q = 0; q < soffs.size(); q++) if (soffs[q] == d) { code = (int)q; break; }
+              guess[sl] = (uint8_t)code;
+            }
+            scode[(size_t)(pos0 + (int64_t)sl * SELL_H)] = (uint8_t)code;
+            if (sval) (*sval)[(size_t)(pos0 + (int64_t)sl * SELL_H)] = ca[k0 + sl];
+          }
+        }
+        for (int sl = len; sl < L; sl++) { /* padding */
+          scode[(size_t)(pos0 + (int64_t)sl * SELL_H)] = 0;
+          if (sval) (*sval)[(size_t)(pos0 + (int64_t)sl * SELL_H)] = 0.0;
+        }
+      }
+    }
+  });
+  for (int k = 0; k < 16; k++) { scode[(size_t)P + k] = 0; if (sval) (*sval)[(size_t)P + k] = 0.0; }
   return 1;
 }
 
-static void fill_sell_values(const std::vector<int32_t> &rp, int32_t m, const double *ca, const std::vector<int64_t> &sptr, std::vector<double> &sval)
+static void fill_sell_values(const std::vector<int32_t> &rp, int32_t m, const double *ca, const std::vector<int64_t> &sptr, raw_dvec &sval)
 {
   const int32_t S = (m + SELL_H - 1) / SELL_H;
-  sval.assign((size_t)sptr[(size_t)S] + 16, 0.0);
-  for (int32_t b = 0; b < S; b++)
-    for (int32_t r = b * SELL_H; r < m && r < (b + 1) * SELL_H; r++) {
-      const int32_t k0 = rp[(size_t)r];
-      const int     len = rp[(size_t)r + 1] - k0;
-      const int64_t pos0 = sptr[(size_t)b] + (r - b * SELL_H);
-      for (int sl = 0; sl < len; sl++) sval[(size_t)(pos0 + (int64_t)sl * SELL_H)] = ca[k0 + sl];
+  const int64_t P = sptr[(size_t)S];
+  sval.resize((size_t)P + 16);
+  par_chunks(S, setup_threads(rp[(size_t)m]), [&](int, int64_t b0, int64_t b1) {
+    for (int64_t b = b0; b < b1; b++) {
+      const int64_t base = sptr[(size_t)b];
+      const int     L = (int)((sptr[(size_t)b + 1] - base) / SELL_H);
+      for (int64_t r = b * SELL_H; r < (b + 1) * SELL_H; r++) {
+        const int64_t pos0 = base + (r - b * SELL_H);
+        int           len = 0;
+        if (r < m) {
+          const int32_t k0 = rp[(size_t)r];
+          len = rp[(size_t)r + 1] - k0;
+          for (int sl = 0; sl < len; sl++) sval[(size_t)(pos0 + (int64_t)sl * SELL_H)] = ca[k0 + sl];
+        }
+        for (int sl = len; sl < L; sl++) sval[(size_t)(pos0 + (int64_t)sl * SELL_H)] = 0.0;
+      }
     }
+  });
+  for (int k = 0; k < 16; k++) sval[(size_t)P + k] = 0.0;
 }
 
 /* ---- pair dictionary -------------------------------------------------------------------------------------------------------------
@@ -1336,36 +1435,72 @@ static void fill_sell_values(const std::vector<int32_t> &rp, int32_t m, const do
    gather loop of scripts/micro/gather_rate.hip (1.17 T/s). */
 static int g_vd_mode = -1;
 
-static int build_pairs(const std::vector<uint8_t> &scode, const std::vector<double> &sval, int64_t P, const std::vector<int32_t> &soffs,
+static int build_pairs(const std::vector<uint8_t> &scode, const raw_dvec &sval, int64_t P, const std::vector<int32_t> &soffs,
                        std::vector<uint8_t> &pcode, std::vector<int32_t> &poffs, std::vector<double> &pvals)
 {
   struct Slot { uint64_t bits; int32_t code; int32_t pair; };
-  const int        HB = 2048; /* open addressing, load <= 1/8 */
-  std::vector<Slot> tab((size_t)HB, Slot{0, -1, -1});
-  poffs.clear(); pvals.clear();
-  pcode.assign((size_t)P + 16, 0);
-  uint64_t lastbits = 0;
-  int      lastcode = -1, lastpair = 0;
-  for (int64_t p = 0; p < P; p++) {
-    uint64_t bits;
-    memcpy(&bits, &sval[(size_t)p], sizeof(bits));
-    const int code = scode[(size_t)p];
-    if (code == lastcode && bits == lastbits) { pcode[(size_t)p] = (uint8_t)lastpair; continue; }
-    size_t h = (size_t)((((bits * 0x9E3779B97F4A7C15ull) >> 40) ^ ((uint64_t)code * 0x9E37u)) & (uint64_t)(HB - 1));
-    for (;; h = (h + 1) & (HB - 1)) {
+  struct Found { uint64_t bits; int32_t code; };
+  const int HB = 2048; /* open addressing, load <= 1/8 */
+  auto      hash = [](uint64_t bits, int code) { return (size_t)((((bits * 0x9E3779B97F4A7C15ull) >> 40) ^ ((uint64_t)code * 0x9E37u)) & (uint64_t)(HB - 1)); };
+  /* looks (code, bits) up in tab; adds it as pair `next` when absent and next >= 0; returns the pair or -1 */
+  auto lookup = [&](std::vector<Slot> &tab, uint64_t bits, int code, int next) {
+    for (size_t h = hash(bits, code);; h = (h + 1) & (HB - 1)) {
       Slot &sl = tab[h];
       if (sl.pair < 0) {
-        if (poffs.size() >= SELL_MAX_OFFS) return 0;
-        sl.bits = bits; sl.code = code; sl.pair = (int32_t)poffs.size();
-        poffs.push_back(soffs[(size_t)code]);
-        pvals.push_back(sval[(size_t)p]);
-        break;
+        if (next < 0) return -1;
+        sl.bits = bits; sl.code = code; sl.pair = next;
+        return next;
       }
-      if (sl.bits == bits && sl.code == code) break;
+      if (sl.bits == bits && sl.code == code) return (int)sl.pair;
     }
-    lastbits = bits; lastcode = code; lastpair = tab[h].pair;
-    pcode[(size_t)p] = (uint8_t)lastpair;
-  }
+  };
+  const int T = setup_threads(P);
+  /* the pairs, numbered by first appearance: every chunk lists its own in that order, the lists are merged in chunk order */
+  std::vector<std::vector<Found>> local((size_t)T);
+  std::atomic<int>                bad(0);
+  par_chunks(P, T, [&](int c, int64_t p0, int64_t p1) {
+    std::vector<Slot>   tab((size_t)HB, Slot{0, -1, -1});
+    std::vector<Found> &mine = local[(size_t)c];
+    uint64_t            lastbits = 0;
+    int                 lastcode = -1;
+    for (int64_t p = p0; p < p1; p++) {
+      uint64_t bits;
+      memcpy(&bits, &sval[(size_t)p], sizeof(bits));
+      const int code = scode[(size_t)p];
+      if (code == lastcode && bits == lastbits) continue;
+      lastbits = bits; lastcode = code;
+      if (lookup(tab, bits, code, (int)mine.size()) == (int)mine.size()) {
+        if (mine.size() >= SELL_MAX_OFFS) { bad = 1; return; }
+        mine.push_back(Found{bits, code});
+      }
+    }
+  });
+  if (bad) return 0;
+  std::vector<Slot> gtab((size_t)HB, Slot{0, -1, -1});
+  poffs.clear(); pvals.clear();
+  for (const auto &mine : local)
+    for (const Found &f : mine)
+      if (lookup(gtab, f.bits, f.code, (int)poffs.size()) == (int)poffs.size()) {
+        if (poffs.size() >= SELL_MAX_OFFS) return 0;
+        double v;
+        memcpy(&v, &f.bits, sizeof(v));
+        poffs.push_back(soffs[(size_t)f.code]);
+        pvals.push_back(v);
+      }
+  pcode.resize((size_t)P + 16);
+  par_chunks(P, T, [&](int, int64_t p0, int64_t p1) {
+    std::vector<Slot> tab(gtab);
+    uint64_t          lastbits = 0;
+    int               lastcode = -1, lastpair = 0;
+    for (int64_t p = p0; p < p1; p++) {
+      uint64_t bits;
+      memcpy(&bits, &sval[(size_t)p], sizeof(bits));
+      const int code = scode[(size_t)p];
+      if (code != lastcode || bits != lastbits) { lastpair = lookup(tab, bits, code, -1); lastbits = bits; lastcode = code; }
+      pcode[(size_t)p] = (uint8_t)lastpair;
+    }
+  });
+  for (int k = 0; k < 16; k++) pcode[(size_t)P + k] = 0;
   return 1;
 }
 
@@ -1402,21 +1537,26 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
   const int32_t         S = A->sell_nslices;
   std::vector<uint32_t> rmask((size_t)S * SELL_H + PHIP_THREADS * 8 + 2, 0u); /* padded to whole workgroups of spmv_dmask4_kernel / spmv_dmaskg_kernel */
   const std::vector<int32_t> &rp = *A->h_rowptr;
-  for (int32_t r = 0; r < A->m; r++) {
-    const int32_t b = r / SELL_H;
-    const int64_t pos0 = (*A->h_sptr)[(size_t)b] + (r - b * SELL_H);
-    const int     len = rp[(size_t)r + 1] - rp[(size_t)r];
-    int           last = -1, lastoff = 0;
-    uint32_t      mk = 0;
-    for (int sl = 0; sl < len; sl++) {
-      const int q = rank[pcode[(size_t)(pos0 + (int64_t)sl * SELL_H)]];
-      const int off = poffs[(size_t)order[q]];
-      if (q <= last || (last >= 0 && off <= lastoff)) { free_dmask(A); return 0; }
-      last = q; lastoff = off;
-      mk |= 1u << q;
+  const int        T = setup_threads(A->sell_padded);
+  std::atomic<int> unordered(0);
+  par_chunks(A->m, T, [&](int, int64_t r0, int64_t r1) {
+    for (int64_t r = r0; r < r1; r++) {
+      const int64_t b = r / SELL_H;
+      const int64_t pos0 = (*A->h_sptr)[(size_t)b] + (r - b * SELL_H);
+      const int     len = rp[(size_t)r + 1] - rp[(size_t)r];
+      int           last = -1, lastoff = 0;
+      uint32_t      mk = 0;
+      for (int sl = 0; sl < len; sl++) {
+        const int q = rank[pcode[(size_t)(pos0 + (int64_t)sl * SELL_H)]];
+        const int off = poffs[(size_t)order[q]];
+        if (q <= last || (last >= 0 && off <= lastoff)) { unordered = 1; return; }
+        last = q; lastoff = off;
+        mk |= 1u << q;
+      }
+      rmask[(size_t)r] = mk;
     }
-    rmask[(size_t)r] = mk;
-  }
+  });
+  if (unordered) { free_dmask(A); return 0; }
   int32_t offs[DMASK_MAX_PAIRS] = {0};
   double  vals[DMASK_MAX_PAIRS] = {0.0};
   for (int q = 0; q < npairs; q++) { offs[q] = poffs[(size_t)order[q]]; vals[q] = pvals[(size_t)order[q]]; }
@@ -1453,7 +1593,8 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
      a wave stays empty (the places of a window that carry no pair) */
   const size_t nwaves = (((size_t)A->m + DMG_WG_ROWS - 1) / DMG_WG_ROWS) * (PHIP_THREADS / 64);
   std::vector<unsigned long long> tmask(std::max<size_t>(nwaves, 1) * DMG_WORDS * 4, 0ull);
-  for (size_t wv = 0; wv < nwaves; wv++) {
+  par_chunks((int64_t)nwaves, T, [&](int, int64_t wv0, int64_t wv1) {
+  for (int64_t wv = wv0; wv < wv1; wv++) {
     const int64_t first = (int64_t)wv * DMG_WAVE_ROWS;
     const int     nrows = (int)std::min<int64_t>(DMG_WAVE_ROWS, std::max<int64_t>((int64_t)A->m - first, 0));
     uint32_t      any = 0u, all = ~0u;
@@ -1468,6 +1609,7 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
     for (int k = 0; k < nrows; k++) /* ... and take out the few rows that miss the pair */
       for (uint32_t miss = part & ~rmask[(size_t)(first + k)]; miss; miss &= miss - 1) tw[__builtin_ctz(miss) * 4 + (k & 3)] &= ~(1ull << (k >> 2));
   }
+  });
   hipStream_t st = A->ctx->stream;
   if (!A->d_rmask) {
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_tmask, sizeof(unsigned long long) * tmask.size()));
@@ -1490,7 +1632,7 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
 }
 
 /* scode / sval: the SELL-dict arrays on the host; soffs: the diagonal table (its first sell_noffs entries) */
-static int setup_pairs(phip_mat A, const std::vector<uint8_t> &scode, const std::vector<double> &sval, const std::vector<int32_t> &soffs)
+static int setup_pairs(phip_mat A, const std::vector<uint8_t> &scode, const raw_dvec &sval, const std::vector<int32_t> &soffs)
 {
   const int was_on = A->vd_built ? A->vd_on : 1;
   if (g_vd_mode < 0) g_vd_mode = getenv("PHIP_VALUE_DICT") ? atoi(getenv("PHIP_VALUE_DICT")) : 1;
@@ -1498,7 +1640,9 @@ static int setup_pairs(phip_mat A, const std::vector<uint8_t> &scode, const std:
   std::vector<uint8_t> pcode;
   std::vector<int32_t> poffs;
   std::vector<double>  pvals;
+  SetupClock clk;
   if (!build_pairs(scode, sval, A->sell_padded, soffs, pcode, poffs, pvals)) { free_pairs(A); return 0; }
+  clk.lap("    build_pairs");
   /* the grouped copy for spmv_pair_kernel */
   const int32_t S = A->sell_nslices;
   std::vector<int64_t> pptr((size_t)S + 1, 0);
@@ -1507,17 +1651,20 @@ static int setup_pairs(phip_mat A, const std::vector<uint8_t> &scode, const std:
     pptr[(size_t)b + 1] = pptr[(size_t)b] + ((L + 3) / 4) * SELL_H;
   }
   std::vector<uint32_t> pgrp((size_t)pptr[(size_t)S] + 4, 0u);
-  for (int32_t b = 0; b < S; b++) {
-    const int64_t  base = (*A->h_sptr)[(size_t)b], L = ((*A->h_sptr)[(size_t)b + 1] - base) / SELL_H;
-    const uint8_t *src = pcode.data() + base;
-    uint32_t      *dst = pgrp.data() + pptr[(size_t)b];
-    for (int64_t sl = 0; sl < L; sl++) {
-      const int      sh = 8 * (int)(sl & 3);
-      uint32_t      *row = dst + (sl >> 2) * SELL_H;
-      const uint8_t *from = src + sl * SELL_H;
-      for (int r = 0; r < SELL_H; r++) row[r] |= (uint32_t)from[r] << sh;
+  par_chunks(S, setup_threads(A->sell_padded), [&](int, int64_t b0, int64_t b1) {
+    for (int64_t b = b0; b < b1; b++) {
+      const int64_t  base = (*A->h_sptr)[(size_t)b], L = ((*A->h_sptr)[(size_t)b + 1] - base) / SELL_H;
+      const uint8_t *src = pcode.data() + base;
+      uint32_t      *dst = pgrp.data() + pptr[(size_t)b];
+      for (int64_t sl = 0; sl < L; sl++) {
+        const int      sh = 8 * (int)(sl & 3);
+        uint32_t      *row = dst + (sl >> 2) * SELL_H;
+        const uint8_t *from = src + sl * SELL_H;
+        for (int r = 0; r < SELL_H; r++) row[r] |= (uint32_t)from[r] << sh;
+      }
     }
-  }
+  });
+  clk.lap("    pair codes grouped");
   hipStream_t st = A->ctx->stream;
   if (!A->d_pgrp) {
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_pgrp, sizeof(uint32_t) * pgrp.size()));
@@ -1529,6 +1676,7 @@ static int setup_pairs(phip_mat A, const std::vector<uint8_t> &scode, const std:
   {
     int rc = setup_dmask(A, pcode, poffs, pvals, A->vd_npairs);
     if (rc) return rc;
+    clk.lap("    diagonal masks");
   }
   poffs.resize(SELL_MAX_OFFS, 0); pvals.resize(SELL_MAX_OFFS, 0.0);
   A->pgrp_dwords = pptr[(size_t)S];
@@ -1561,8 +1709,10 @@ static int setup_sell(phip_mat A, const int32_t *h_j, const double *h_a)
   }
   std::vector<uint8_t> slen, scode;
   std::vector<int32_t> soffs;
-  std::vector<double>  sval;
+  raw_dvec             sval;
+  SetupClock           clk;
   const int ok = build_sell(*A->h_rowptr, A->m, A->n, h_j, h_a, *A->h_sptr, slen, soffs, &sval, scode);
+  clk.lap("  build_sell");
   if (!ok) {
     PHIP_REQUIRE(A->fmt_user != 2, PHIP_ERR_SUP, "phip_mat: matrix is not eligible for the SELL-dict layout (more than %d distinct diagonals, a row longer than 255, or padding above %.0f %%)", SELL_MAX_OFFS, (SELL_MAX_PAD - 1) * 100);
     return 0;
@@ -1614,8 +1764,10 @@ static int setup_sell(phip_mat A, const int32_t *h_j, const double *h_a)
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_scl, scl.data(), sizeof(int32_t) * scl.size(), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_sldsoff, sldsoff.data(), sizeof(int32_t) * SELL_MAX_OFFS, hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipStreamSynchronize(st));
+  clk.lap("  SELL arrays to the device");
   int rc = setup_pairs(A, scode, sval, soffs);
   if (rc) return rc;
+  clk.lap("  setup_pairs (+ masks)");
   A->h_scode = new std::vector<uint8_t>();
   A->h_scode->swap(scode);
   A->h_soffs = new std::vector<int32_t>(soffs);
@@ -1644,11 +1796,13 @@ extern "C" int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t
   PHIP_REQUIRE(m >= 0 && n >= 0, PHIP_ERR_ARG_OUTOFRANGE, "phip_mat_create: negative size %d x %d", m, n);
   PHIP_REQUIRE(h_i[0] == 0, PHIP_ERR_ARG_WRONGSTATE, "phip_mat_create: i[0] = %d, matrix not assembled", h_i[0]);
   const int64_t nnz = h_i[m];
+  SetupClock    clk;
   PHIP_REQUIRE(nnz == 0 || (h_j && h_a), PHIP_ERR_ARG_NULL, "phip_mat_create: null j/a with nz=%lld", (long long)nnz);
   if (use_cprow) PHIP_REQUIRE(h_cprow_i && (h_cprow_rindex || !cprow_nrows), PHIP_ERR_ARG_NULL, "phip_mat_create: compressed row arrays missing");
   /* operand checks the kernel relies on: monotone row pointer, column range */
   for (int32_t r = 0; r < m; r++) PHIP_REQUIRE(h_i[r + 1] >= h_i[r], PHIP_ERR_ARG_WRONGSTATE, "phip_mat_create: row pointer decreases at row %d", r);
   for (int64_t k = 0; k < nnz; k++) PHIP_REQUIRE(h_j[k] >= 0 && h_j[k] < n, PHIP_ERR_ARG_OUTOFRANGE, "phip_mat_create: column %d out of range [0,%d) at entry %lld", h_j[k], n, (long long)k);
+  clk.lap("operand checks");
   if (ctx->device >= 0) PHIP_CHECK_HIP(hipSetDevice(ctx->device));
   phip_mat A = new phip_mat_s();
   memset(A, 0, sizeof(*A));
@@ -1689,14 +1843,18 @@ extern "C" int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t
     if (A->R) PHIP_CHECK_HIP(hipMemcpyAsync(A->d_ridx, h_cprow_rindex, sizeof(int32_t) * (size_t)A->R, hipMemcpyHostToDevice, ctx->stream));
   }
   PHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  clk.lap("CSR to the device");
   int rc = upload_plan(A);
   if (rc) return rc;
+  clk.lap("row-block plan");
   if ((rc = setup_sell(A, h_j, h_a))) return rc;
+  clk.lap("SELL / pairs / masks");
   {
     std::vector<int32_t> order, newcol;
     if ((rc = setup_hot(A, h_j, order, newcol))) return rc;
     if ((rc = setup_lds(A, h_j, order, newcol))) return rc;
   }
+  clk.lap("hot columns");
   *out = A;
   return 0;
 }
@@ -1714,7 +1872,7 @@ extern "C" int phip_mat_update_values(phip_mat A, const double *h_a)
   PHIP_CHECK_HIP(hipSetDevice(A->ctx->device));
   if (A->nnz) PHIP_CHECK_HIP(hipMemcpyAsync(A->d_val, h_a, sizeof(double) * (size_t)A->nnz, hipMemcpyHostToDevice, A->ctx->stream));
   if (A->sell_built) {
-    std::vector<double> sval;
+    raw_dvec sval;
     fill_sell_values(*A->h_rowptr, A->m, h_a, *A->h_sptr, sval);
     PHIP_CHECK_HIP(hipMemcpyAsync(A->d_sval, sval.data(), sizeof(double) * sval.size(), hipMemcpyHostToDevice, A->ctx->stream));
     PHIP_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
@@ -2282,6 +2440,13 @@ extern "C" int phip_mat_hot_columns_info(phip_mat A, int *built, int *in_use, do
 
 /* hot columns resident in LDS (setup_lds): on = 0 runs the row-block kernel, 1 the wave kernel built at creation (error if none was
    built).  info: built / in use / K / share of the nonzeros whose column is one of the K. */
+extern "C" int phip_set_setup_threads(int nthreads)
+{
+  PHIP_REQUIRE(nthreads >= 0 && nthreads <= 64, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_setup_threads: %d (0: default, at most 64)", nthreads);
+  g_setup_threads = nthreads;
+  return 0;
+}
+
 extern "C" int phip_set_dmask_kernel(int kind)
 {
   PHIP_REQUIRE(kind == 0 || kind == 4 || kind == 5, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_dmask_kernel: %d (0 by size, 4 bit sets per row, 5 group descriptors)", kind);

@@ -126,6 +126,50 @@ def test_default_group_descriptor_mask_kernel(ctx):
     ctx.check(L.phip_mat_destroy(A))
 
 
+def test_setup_threads_do_not_change_the_layout(ctx):
+    """The host passes of phip_mat_create run on several threads from 2^20 stored entries on; tables numbered by first appearance
+    (diagonals, pairs) must come out as on one thread: same counts, same products bit for bit -- for a stencil (pair dictionary, masks),
+    a matrix with a value of its own per entry (streamed SELL values) and after phip_mat_update_values."""
+    from petsc_amd import generators as G
+    L = ctx.lib
+    ai, aj, aa = G.stencil_rows_native(27, 40, 37, 41, 0, 40 * 37 * 41)
+    m = len(ai) - 1
+    assert len(aa) >= (1 << 20)
+    rng = np.random.default_rng(12)
+    varied = aa * rng.uniform(0.5, 1.5, len(aa))
+    x = rng.uniform(-1.0, 1.0, m)
+    dx, dy = ctx.to_device(x), ctx.to_device(np.zeros(m))
+    out = {}
+    for nt in (1, 5, 16):
+        ctx.check(L.phip_set_setup_threads(nt))
+        try:
+            for name, vals in (("stencil", aa), ("varied", varied)):
+                A = ctx.mat_create(m, m, ai, aj, vals)
+                f, nd, pad = C.c_int(), C.c_int32(), C.c_int64()
+                ctx.check(L.phip_mat_format_info(A, C.byref(f), C.byref(nd), C.byref(pad)))
+                vb, vu, vn = C.c_int(), C.c_int(), C.c_int32()
+                ctx.check(L.phip_mat_value_dict_info(A, C.byref(vb), C.byref(vu), C.byref(vn)))
+                ctx.check(L.phip_mat_mult(A, dx, dy))
+                y1 = ctx.to_host(dy, m)
+                ctx.check(L.phip_mat_update_values(A, (varied if name == "stencil" else aa).ctypes.data_as(C.POINTER(C.c_double))))
+                ctx.check(L.phip_mat_mult(A, dx, dy))
+                out[nt, name] = ((f.value, nd.value, pad.value, vb.value, vn.value), y1, ctx.to_host(dy, m))
+                ctx.check(L.phip_mat_destroy(A))
+        finally:
+            ctx.check(L.phip_set_setup_threads(0))
+    assert out[1, "stencil"][0][3] == 1 and out[1, "varied"][0][3] == 0        # a pair dictionary / none
+    for nt in (5, 16):
+        for name in ("stencil", "varied"):
+            assert out[nt, name][0] == out[1, name][0], (nt, name)
+            assert np.array_equal(out[nt, name][1], out[1, name][1]) and np.array_equal(out[nt, name][2], out[1, name][2]), (nt, name)
+    assert np.array_equal(out[1, "stencil"][2], out[1, "varied"][1])            # updated to the other's values: the other's product
+    rows = np.arange(0, m, 211)
+    ref = np.array([np.dot(aa[ai[r]:ai[r + 1]], x[aj[ai[r]:ai[r + 1]]]) for r in rows])
+    assert np.abs(out[16, "stencil"][1][rows] - ref).max() <= 1e-12 * np.abs(ref).max()
+    for p_ in (dx, dy):
+        ctx.free(p_)
+
+
 def test_default_nontemporal_elementwise(ctx):
     """vectors of 6.5 M entries (52 MB >= 48 MiB): the elementwise kernels, the batch kernel and the KSPCG batch read (and partly store)
     past the caches by default; the same calls with the feature off must give the same bits, and the closed forms on a sample."""
