@@ -443,7 +443,11 @@ def main():
             hc = comm.hip_comm()
             rr, ss = C.c_int(), C.c_int()
             L.phip_comm_rank_size(hc, C.byref(rr), C.byref(ss))
+            ipcn = C.c_ulonglong()
+            L.phip_halo_ipc_count(C.byref(ipcn))
             out["multi_gpu"] = {"backend": backend, "rccl_ranks": ss.value if backend == "rccl" else 0, "comm_ranks": ss.value, "halo_rank0": halo,
+                                "ghost_exchange": "peer writes into hipIpc-mapped receive buffers (PHIP_HALO_IPC=1)" if ipcn.value else
+                                ("grouped ncclSend/ncclRecv on a second stream" if backend == "rccl" else "staged through host shared memory (rehearsal backend)"),
                                 "reductions": "host shared-memory ring" if not os.environ.get("PETSCHIP_DEVICE_ALLREDUCE") else "ncclAllReduce"}
     for o in (ksp, x, b, A):
         o.destroy()

@@ -321,6 +321,12 @@ int phip_comm_barrier(phip_comm comm);
 int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_procs, const int32_t *to_starts, const int32_t *to_indices,
                      int32_t from_n, const int32_t *from_procs, const int32_t *from_starts, phip_halo *halo);
 int phip_halo_destroy(phip_halo halo);
+/* PHIP_HALO_IPC=1 (set alike on every rank before phip_halo_create; backends "rccl" and "shm", ranks of one node): the forward exchange
+ * as PEER WRITES -- the ranks map each other's receive buffers (hipIpcGetMemHandle / hipIpcOpenMemHandle), the pack kernel of
+ * phip_halo_begin stores x[to_indices] straight into them and raises a flag word there; phip_halo_end launches one kernel that waits
+ * for the flags, copies to lvec and acknowledges.  No send/receive kernels, no second stream.  Off by default: it runs between
+ * processes sharing one GPU (tests) but has not yet run between GPUs.  phip_halo_ipc_count: exchanges this process made that way. */
+int phip_halo_ipc_count(unsigned long long *n);
 int phip_halo_begin(phip_halo halo, const double *d_x_local, double *d_lvec);
 int phip_halo_end(phip_halo halo);
 /* The same plan run backwards with ADD_VALUES (VecScatterBegin/End(Mvctx, lvec, y, ADD_VALUES, SCATTER_REVERSE) of

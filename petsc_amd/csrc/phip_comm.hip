@@ -30,6 +30,7 @@
 #include <time.h>
 #include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -162,6 +163,18 @@ struct phip_halo_s {
   int32_t  *d_tgt, *d_tptr, *d_tpos;
   const double *rev_lvec;
   std::vector<int32_t> cnt; /* shm backend: cnt[p*size+q] = entries rank p sends to rank q in the forward exchange */
+  /* peer-write exchange (PHIP_HALO_IPC=1, ranks of one node): the pack kernel stores straight into the neighbours' receive buffers */
+  int                  ipc_on;
+  unsigned long long   ipc_seq;      /* number of the exchange under way, 1, 2, ... */
+  double              *ipc_recv;     /* [nrecv] what the neighbours store; copied to lvec by the wait kernel */
+  unsigned long long  *ipc_sync;     /* [from_n] flags (a sender stores seq once its segment is complete), [to_n] acknowledgements (a receiver
+                                        stores seq once it has copied the segment out), [2] arrival counters of the two kernels */
+  int32_t             *d_send_seg;   /* [nsend] neighbour (index into to_procs) of every send entry */
+  int32_t             *d_to_starts;  /* [to_n + 1] */
+  double             **d_peer_recv;  /* [to_n] where neighbour i wants my segment (its ipc_recv + its offset for me) */
+  unsigned long long **d_peer_flag;  /* [to_n] my flag word in neighbour i's ipc_sync */
+  unsigned long long **d_peer_ack;   /* [from_n] my acknowledgement word in neighbour j's ipc_sync */
+  std::vector<void *>  ipc_opened;   /* mappings to close */
 };
 
 /* ---- host reduction ring: attach / detach / one round -------------------------------------------------------------------- */
@@ -635,6 +648,167 @@ __global__ __launch_bounds__(PHIP_THREADS) void halo_pack_kernel(int32_t n, cons
   for (int64_t i = (int64_t)blockIdx.x * PHIP_THREADS + threadIdx.x; i < n; i += stride) y[i] = x[idx[i]];
 }
 
+/* ---- peer-write ghost exchange (PHIP_HALO_IPC=1) ------------------------------------------------------------------------------
+   Ranks of one node map each other's receive buffers (hipIpcGetMemHandle / hipIpcOpenMemHandle, exchanged once at phip_halo_create)
+   and the pack kernel stores x[to_indices] straight into them: no send/receive kernels, no second stream, no staging -- one launch in
+   phip_halo_begin, one in phip_halo_end.  Hand-off per exchange number seq (MI355X_MICROARCH.md, hand-offs):
+     sender    every workgroup: stores, __threadfence_system, arrival counter; the last one stores seq into its flag word at each
+               neighbour (system scope).  Before storing, the kernel waits until each neighbour acknowledged exchange seq - 1.
+     receiver  (phip_halo_end) waits for the flags of all its neighbours, copies its receive buffer to lvec with loads that bypass
+               the caches, and the last workgroup stores seq into its acknowledgement word at each sender.
+   Every wait is bounded: a kernel that gives up leaves the context's error word set (the next reduction reports PHIP_ERR_LIB) and ends.
+   The reverse exchange (MatMultTranspose) keeps the backend's own path.  Works between processes that share one GPU (the rehearsal
+   of tests/test_host_gpu.py) and, by construction, between the GPUs of a node; the latter has not run yet. */
+#define IPC_SPIN_MAX (1 << 24)
+static std::atomic<unsigned long long> g_ipc_exchanges(0);
+extern "C" int phip_halo_ipc_count(unsigned long long *n)
+{
+  PHIP_REQUIRE(n, PHIP_ERR_ARG_NULL, "phip_halo_ipc_count: null argument");
+  *n = g_ipc_exchanges.load();
+  return 0;
+}
+__device__ __forceinline__ unsigned long long ipc_load_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ bool ipc_wait_ge(const unsigned long long *p, unsigned long long want)
+{
+  for (int spin = 0; spin < IPC_SPIN_MAX; spin++) {
+    if (ipc_load_sys(p) >= want) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return true; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(PHIP_THREADS) void halo_pack_ipc_kernel(int32_t nsend, int32_t to_n, const int32_t *__restrict__ to_starts, const int32_t *__restrict__ seg,
+                                                                   const int32_t *__restrict__ idx, const double *__restrict__ x, double *const *__restrict__ peer_recv,
+                                                                   unsigned long long *const *__restrict__ peer_flag, const unsigned long long *acks,
+                                                                   unsigned long long seq, unsigned int *counter, unsigned int *err)
+{
+  __shared__ int last;
+  const int      t = threadIdx.x;
+  if (t < to_n && !ipc_wait_ge(&acks[t], seq - 1) && err) __hip_atomic_store(err, 0x1bc00001u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
+  for (int64_t k = (int64_t)blockIdx.x * PHIP_THREADS + t; k < nsend; k += stride) {
+    const int i = seg[k];
+    peer_recv[i][k - to_starts[i]] = x[idx[k]];
+  }
+  __threadfence_system(); /* this workgroup's stores are visible to the neighbours before it counts as arrived */
+  __syncthreads();
+  if (t == 0) last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  if (t < to_n) __hip_atomic_store(peer_flag[t], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (t == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(PHIP_THREADS) void halo_wait_ipc_kernel(int32_t nrecv, int32_t from_n, const unsigned long long *flags, unsigned long long seq,
+                                                                   const double *recv, double *__restrict__ lvec, unsigned long long *const *__restrict__ peer_ack,
+                                                                   unsigned int *counter, unsigned int *err)
+{
+  __shared__ int last;
+  const int      t = threadIdx.x;
+  if (t < from_n && !ipc_wait_ge(&flags[t], seq) && err) __hip_atomic_store(err, 0x1bc00002u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
+  for (int64_t k = (int64_t)blockIdx.x * PHIP_THREADS + t; k < nrecv; k += stride) /* written by another agent: not through this one's caches */
+    lvec[k] = __longlong_as_double((long long)ipc_load_sys(reinterpret_cast<const unsigned long long *>(recv) + k));
+  __syncthreads();
+  if (t == 0) last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  if (t < from_n) __hip_atomic_store(peer_ack[t], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (t == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static int shm_allgatherv(phip_comm c, const void *mine, size_t my_bytes, std::vector<std::vector<unsigned char>> &all);
+
+/* every rank publishes {handles of its receive buffer and sync block, its receive and send plans}; each rank maps what its neighbours
+   published and works out where its segments and signals go.  Collective; fails on every rank alike or on none. */
+static int halo_ipc_setup(phip_halo h)
+{
+  phip_comm c = h->comm;
+  phip_ctx  ctx = c->ctx;
+  PHIP_REQUIRE(h->to_n <= PHIP_THREADS && h->from_n <= PHIP_THREADS, PHIP_ERR_SUP, "peer-write halo: more than %d neighbours", PHIP_THREADS);
+  const size_t nsync = (size_t)h->from_n + (size_t)h->to_n + 2;
+  PHIP_CHECK_HIP(hipMalloc((void **)&h->ipc_recv, sizeof(double) * ((size_t)h->nrecv + 2)));
+  PHIP_CHECK_HIP(hipMalloc((void **)&h->ipc_sync, sizeof(unsigned long long) * nsync));
+  PHIP_CHECK_HIP(hipMemset(h->ipc_sync, 0, sizeof(unsigned long long) * nsync));
+  struct Head { hipIpcMemHandle_t recv, sync; int32_t from_n, to_n, ok, pad; };
+  std::vector<unsigned char> rec(sizeof(Head) + sizeof(int32_t) * ((size_t)2 * h->from_n + 1 + (size_t)h->to_n));
+  Head                       hd;
+  memset(&hd, 0, sizeof(hd));
+  hd.from_n = h->from_n; hd.to_n = h->to_n;
+  hd.ok = hipIpcGetMemHandle(&hd.recv, h->ipc_recv) == hipSuccess && hipIpcGetMemHandle(&hd.sync, h->ipc_sync) == hipSuccess;
+  (void)hipGetLastError();
+  memcpy(rec.data(), &hd, sizeof(hd));
+  int32_t *tail = reinterpret_cast<int32_t *>(rec.data() + sizeof(Head));
+  for (int j = 0; j < h->from_n; j++) tail[j] = h->from_procs[(size_t)j];
+  for (int j = 0; j <= h->from_n; j++) tail[h->from_n + j] = h->from_starts[(size_t)j];
+  for (int i = 0; i < h->to_n; i++) tail[2 * h->from_n + 1 + i] = h->to_procs[(size_t)i];
+  std::vector<std::vector<unsigned char>> all;
+  int rc = shm_allgatherv(c, rec.data(), rec.size(), all);
+  if (rc) return rc;
+  int allok = 1;
+  for (int p = 0; p < c->size; p++) { Head q; memcpy(&q, all[(size_t)p].data(), sizeof(q)); allok = allok && q.ok; }
+  PHIP_REQUIRE(allok, PHIP_ERR_LIB, "peer-write halo: hipIpcGetMemHandle failed on some rank");
+  std::vector<double *>             peer_recv((size_t)h->to_n + 1, NULL);
+  std::vector<unsigned long long *> peer_flag((size_t)h->to_n + 1, NULL), peer_ack((size_t)h->from_n + 1, NULL);
+  std::vector<void *>               recv_of((size_t)c->size, NULL), sync_of((size_t)c->size, NULL);
+  auto map_peer = [&](int p) -> int {
+    if (sync_of[(size_t)p]) return 0;
+    Head q;
+    memcpy(&q, all[(size_t)p].data(), sizeof(q));
+    PHIP_CHECK_HIP(hipIpcOpenMemHandle(&recv_of[(size_t)p], q.recv, hipIpcMemLazyEnablePeerAccess));
+    h->ipc_opened.push_back(recv_of[(size_t)p]);
+    PHIP_CHECK_HIP(hipIpcOpenMemHandle(&sync_of[(size_t)p], q.sync, hipIpcMemLazyEnablePeerAccess));
+    h->ipc_opened.push_back(sync_of[(size_t)p]);
+    return 0;
+  };
+  int bad = 0;
+  for (int i = 0; i < h->to_n && !bad; i++) { /* neighbour p receives from me: its plan says where */
+    const int p = h->to_procs[(size_t)i];
+    if (map_peer(p)) { bad = 1; break; }
+    Head q;
+    memcpy(&q, all[(size_t)p].data(), sizeof(q));
+    const int32_t *pt = reinterpret_cast<const int32_t *>(all[(size_t)p].data() + sizeof(Head));
+    int            j = -1;
+    for (int k = 0; k < q.from_n; k++) if (pt[k] == c->rank) j = k;
+    if (j < 0 || pt[q.from_n + j + 1] - pt[q.from_n + j] != h->to_starts[(size_t)i + 1] - h->to_starts[(size_t)i]) { bad = 2; break; }
+    peer_recv[(size_t)i] = (double *)recv_of[(size_t)p] + pt[q.from_n + j];
+    peer_flag[(size_t)i] = (unsigned long long *)sync_of[(size_t)p] + j;
+  }
+  for (int j = 0; j < h->from_n && !bad; j++) { /* neighbour p sends to me: my acknowledgement goes behind its flags */
+    const int p = h->from_procs[(size_t)j];
+    if (map_peer(p)) { bad = 1; break; }
+    Head q;
+    memcpy(&q, all[(size_t)p].data(), sizeof(q));
+    const int32_t *pt = reinterpret_cast<const int32_t *>(all[(size_t)p].data() + sizeof(Head));
+    int            i = -1;
+    for (int k = 0; k < q.to_n; k++) if (pt[2 * q.from_n + 1 + k] == c->rank) i = k;
+    if (i < 0) { bad = 2; break; }
+    peer_ack[(size_t)j] = (unsigned long long *)sync_of[(size_t)p] + q.from_n + i;
+  }
+  /* agree before anyone relies on it */
+  std::vector<int32_t> bads((size_t)c->size);
+  int32_t              mybad = bad;
+  if ((rc = phip_comm_allgather_host(c, &mybad, bads.data(), sizeof(int32_t)))) return rc;
+  for (int p = 0; p < c->size; p++) PHIP_REQUIRE(!bads[(size_t)p], PHIP_ERR_LIB, "peer-write halo: rank %d could not map its neighbours (%s)", p, bads[(size_t)p] == 1 ? "hipIpcOpenMemHandle failed" : "the plans of two neighbours do not match");
+  std::vector<int32_t> seg((size_t)h->nsend + 1, 0);
+  for (int i = 0; i < h->to_n; i++) for (int32_t k = h->to_starts[(size_t)i]; k < h->to_starts[(size_t)i + 1]; k++) seg[(size_t)k] = i;
+  PHIP_CHECK_HIP(hipMalloc((void **)&h->d_send_seg, sizeof(int32_t) * seg.size()));
+  PHIP_CHECK_HIP(hipMalloc((void **)&h->d_to_starts, sizeof(int32_t) * ((size_t)h->to_n + 1)));
+  PHIP_CHECK_HIP(hipMalloc((void **)&h->d_peer_recv, sizeof(void *) * peer_recv.size()));
+  PHIP_CHECK_HIP(hipMalloc((void **)&h->d_peer_flag, sizeof(void *) * peer_flag.size()));
+  PHIP_CHECK_HIP(hipMalloc((void **)&h->d_peer_ack, sizeof(void *) * peer_ack.size()));
+  PHIP_CHECK_HIP(hipMemcpy(h->d_send_seg, seg.data(), sizeof(int32_t) * seg.size(), hipMemcpyHostToDevice));
+  PHIP_CHECK_HIP(hipMemcpy(h->d_to_starts, h->to_starts.data(), sizeof(int32_t) * ((size_t)h->to_n + 1), hipMemcpyHostToDevice));
+  PHIP_CHECK_HIP(hipMemcpy(h->d_peer_recv, peer_recv.data(), sizeof(void *) * peer_recv.size(), hipMemcpyHostToDevice));
+  PHIP_CHECK_HIP(hipMemcpy(h->d_peer_flag, peer_flag.data(), sizeof(void *) * peer_flag.size(), hipMemcpyHostToDevice));
+  PHIP_CHECK_HIP(hipMemcpy(h->d_peer_ack, peer_ack.data(), sizeof(void *) * peer_ack.size(), hipMemcpyHostToDevice));
+  h->ipc_seq = 0;
+  h->ipc_on = 1;
+  return phip_comm_barrier(c); /* nobody stores into a buffer before its owner has zeroed the sync words and everyone has mapped */
+}
+
 extern "C" int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_procs, const int32_t *to_starts, const int32_t *to_indices,
                                 int32_t from_n, const int32_t *from_procs, const int32_t *from_starts, phip_halo *out)
 {
@@ -654,6 +828,7 @@ extern "C" int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_
   phip_ctx ctx = comm->ctx;
   h->d_to_indices = NULL; h->d_sendbuf = NULL; h->lvec = NULL;
   h->ntgt = 0; h->d_tgt = h->d_tptr = h->d_tpos = NULL; h->rev_lvec = NULL;
+  h->ipc_on = 0; h->ipc_seq = 0; h->ipc_recv = NULL; h->ipc_sync = NULL; h->d_send_seg = NULL; h->d_to_starts = NULL; h->d_peer_recv = NULL; h->d_peer_flag = NULL; h->d_peer_ack = NULL;
   if (ctx->device < 0) { *out = h; return 0; } /* planning-only: the plan stays on the host */
   PHIP_CHECK_HIP(hipSetDevice(ctx->device));
   PHIP_CHECK_HIP(hipMalloc((void **)&h->d_to_indices, sizeof(int32_t) * ((size_t)h->nsend + 4)));
@@ -690,6 +865,11 @@ extern "C" int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_
   }
   PHIP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
   PHIP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+  /* PHIP_HALO_IPC=1: the peer-write exchange between the processes of one node (backends rccl and shm); every rank must set it alike */
+  if (comm->size > 1 && (comm->backend == BACKEND_RCCL || comm->backend == BACKEND_SHM) && getenv("PHIP_HALO_IPC") && atoi(getenv("PHIP_HALO_IPC"))) {
+    int rc = halo_ipc_setup(h);
+    if (rc) return rc;
+  }
   *out = h;
   return 0;
 }
@@ -702,6 +882,9 @@ extern "C" int phip_halo_destroy(phip_halo h)
   hipStreamSynchronize(h->comm->ctx->stream);
   hipStreamSynchronize(h->comm->ctx->comm_stream);
   hipFree(h->d_to_indices); hipFree(h->d_sendbuf); hipFree(h->d_tgt); hipFree(h->d_tptr); hipFree(h->d_tpos);
+  if (h->ipc_on) phip_comm_barrier(h->comm); /* no neighbour stores into a buffer that is about to go */
+  for (void *q : h->ipc_opened) hipIpcCloseMemHandle(q);
+  hipFree(h->ipc_recv); hipFree(h->ipc_sync); hipFree(h->d_send_seg); hipFree(h->d_to_starts); hipFree(h->d_peer_recv); hipFree(h->d_peer_flag); hipFree(h->d_peer_ack);
   hipEventDestroy(h->ev_packed); hipEventDestroy(h->ev_done);
   delete h;
   return 0;
@@ -746,6 +929,15 @@ extern "C" int phip_halo_begin(phip_halo h, const double *d_x_local, double *d_l
   PHIP_NEED_DEVICE(ctx, "phip_halo_begin");
   PHIP_FLUSH(ctx);
   PHIP_REQUIRE(c->backend != BACKEND_CALLBACKS, PHIP_ERR_SUP, "phip_halo_begin: the callbacks backend carries set-up traffic only");
+  if (h->ipc_on) { /* one launch: wait for the neighbours' acknowledgement of the last exchange, store into their buffers, raise the flags */
+    h->ipc_seq++;
+    g_ipc_exchanges++;
+    hipLaunchKernelGGL(halo_pack_ipc_kernel, dim3(phip_grid_for(h->nsend > 0 ? h->nsend : 1, 1, 64)), dim3(PHIP_THREADS), 0, ctx->stream, h->nsend, h->to_n, h->d_to_starts,
+                       h->d_send_seg, h->d_to_indices, d_x_local, h->d_peer_recv, h->d_peer_flag, h->ipc_sync + h->from_n, h->ipc_seq,
+                       reinterpret_cast<unsigned int *>(h->ipc_sync + h->from_n + h->to_n), ctx->h_err_dev);
+    PHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (h->nsend) {
     hipLaunchKernelGGL(halo_pack_kernel, dim3(phip_grid_for(h->nsend, 1, 1024)), dim3(PHIP_THREADS), 0, ctx->stream, h->nsend, h->d_to_indices, d_x_local, h->d_sendbuf);
     PHIP_CHECK_HIP(hipGetLastError());
@@ -789,6 +981,12 @@ extern "C" int phip_halo_end(phip_halo h)
   phip_ctx  ctx = c->ctx;
   if (c->size == 1) return 0;
   PHIP_FLUSH(ctx);
+  if (h->ipc_on) { /* wait for the neighbours' flags, copy what they stored to lvec, acknowledge */
+    hipLaunchKernelGGL(halo_wait_ipc_kernel, dim3(phip_grid_for(h->nrecv > 0 ? h->nrecv : 1, 1, 64)), dim3(PHIP_THREADS), 0, ctx->stream, h->nrecv, h->from_n, h->ipc_sync,
+                       h->ipc_seq, h->ipc_recv, h->lvec, h->d_peer_ack, reinterpret_cast<unsigned int *>(h->ipc_sync + h->from_n + h->to_n) + 1, ctx->h_err_dev);
+    PHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (c->backend == BACKEND_RCCL) {
     PHIP_CHECK_HIP(hipStreamWaitEvent(ctx->stream, h->ev_done, 0));
     return 0;

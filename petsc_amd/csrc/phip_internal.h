@@ -9,6 +9,8 @@
 #define PHIP_RED_BLOCKS 4096 /* capacity of the partial-result rows: the largest grid a kernel with a fused reduction may have */
 #define PHIP_RED_GRID 1024   /* grid cap of the vector reduction kernels (2048 measured slower); the summation tree depends on the grid only */
 #define PHIP_THREADS 256
+#define PHIP_RED_RESIDENT 2048 /* workgroups of 256 threads an MI355X holds at once (256 CUs x 8): the largest grid an environment override may give a
+                                  kernel whose last workgroup waits for the others' partial results (reduce_tail) */
 
 #define PHIP_RING 64
 #define PHIP_RING_VALS 8
@@ -28,6 +30,7 @@ struct phip_ctx_s {
   double      *h_result;    // pinned host mirror of d_result
   unsigned long long *h_ll;     // pinned, device-visible: flagged words [2*PHIP_MAX_MVEC] published by the last workgroup of a reduction
   unsigned long long *h_ll_dev; // device address of h_ll
+  unsigned int       *h_err, *h_err_dev; // pinned error word of the reduction kernels (phip_reduce.h) and its device address
   unsigned long long  seq;  // last sequence number issued (its low 32 bits, never 0, are the flag)
   /* by-product reductions (phip_ticket): ring of result slots, device side and pinned host side */
   double      *d_ring;      // [PHIP_RING][PHIP_RING_VALS]

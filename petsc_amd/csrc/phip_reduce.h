@@ -11,6 +11,7 @@ struct RedCtl {
   int                 npub;
   int                 kofs;    /* first partial row / d_out index of this launch */
   int                 accumulate; /* add to d_out[] (written by an earlier kernel of the stream) instead of overwriting it */
+  unsigned int       *err = nullptr; /* the context's pinned error word (device address) or NULL: a collector that gave up waiting leaves its flag there */
 };
 
 /* value k of a result slot, as two flagged 8-byte words (phip_internal.h) */
@@ -86,6 +87,15 @@ __device__ __forceinline__ void partial_get_batch(const unsigned long long *p, i
   for (int j = 0; j < B; j++) v[j] = (i0 + stride * j < n) ? __longlong_as_double((long long)((w0[j] & 0xFFFFFFFFull) | (w1[j] << 32))) : 0.0;
 }
 
+/* the collector gave up (partial_get_batch): besides publishing NaN it leaves the launch's flag in the context's error word, ahead of
+   the results, so that the host call that fetches them fails with PHIP_ERR_LIB instead of handing NaN to the solver */
+__device__ __forceinline__ void reduce_report_timeout(const RedCtl &c)
+{
+  if (!c.err) return;
+  __hip_atomic_store(c.err, c.pflag ? c.pflag : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+}
+
 /* Tail of every reduction kernel.  acc[] holds the workgroup's partials in thread 0.  MODE 0: NV sums.  MODE 1: acc[0] = max,
    acc[1] = NaN flag -> one result (NaN if any flag, bvec2.c:253-258).
    Every workgroup leaves its partials as flagged words (the flag is unique to the launch) and is done.  The workgroup with the highest
@@ -120,6 +130,7 @@ __device__ __forceinline__ void reduce_tail(double (&acc)[NV], double *lds /* un
       m = wave_max(m); f = wave_max(f);
       ok = __all(ok);
       if (lane == 0) {
+        if (!ok) reduce_report_timeout(c);
         const double r = (f > 0.0 || !ok) ? __builtin_nan("") : m;
         c.d_out[c.kofs] = r;
         if (c.h_ll && c.kofs < c.npub) publish_ll(c.h_ll, c.kofs, r, c.seq);
@@ -139,7 +150,7 @@ __device__ __forceinline__ void reduce_tail(double (&acc)[NV], double *lds /* un
       ok = __all(ok);
       if (lane == 0) { /* the result goes to the host straight from the register: no round trip through d_out */
         double r = c.accumulate ? c.d_out[c.kofs + k] + s : s;
-        if (!ok) r = __builtin_nan("");
+        if (!ok) { r = __builtin_nan(""); reduce_report_timeout(c); }
         c.d_out[c.kofs + k] = r;
         if (c.h_ll && c.kofs + k < c.npub) publish_ll(c.h_ll, c.kofs + k, r, c.seq);
       }

@@ -57,6 +57,9 @@ extern "C" int phip_init(int device, phip_ctx *out)
   PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_ll, sizeof(unsigned long long) * 2 * PHIP_MAX_MVEC, hipHostMallocMapped | hipHostMallocCoherent));
   PHIP_CHECK_HIP(hipHostGetDevicePointer((void **)&c->h_ll_dev, c->h_ll, 0));
   memset(c->h_ll, 0, sizeof(unsigned long long) * 2 * PHIP_MAX_MVEC);
+  PHIP_CHECK_HIP(hipHostMalloc((void **)&c->h_err, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  PHIP_CHECK_HIP(hipHostGetDevicePointer((void **)&c->h_err_dev, c->h_err, 0));
+  *c->h_err = 0;
   c->seq = 0;
   PHIP_CHECK_HIP(hipMalloc((void **)&c->d_ring, sizeof(double) * PHIP_RING * PHIP_RING_VALS));
   PHIP_CHECK_HIP(hipMemsetAsync(c->d_ring, 0, sizeof(double) * PHIP_RING * PHIP_RING_VALS, c->stream));
@@ -84,7 +87,7 @@ extern "C" int phip_finalize(phip_ctx c)
   PHIP_FLUSH(c);
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->comm_stream));
-  hipHostFree(c->h_ll); hipFree(c->d_ring); hipHostFree(c->h_ring);
+  hipHostFree(c->h_ll); hipHostFree(c->h_err); hipFree(c->d_ring); hipHostFree(c->h_ring);
   hipFree(c->d_partials); hipFree(c->d_result); hipHostFree(c->h_result); hipFree(c->d_flag); hipHostFree(c->h_flag);
   if (c->prof) {
     for (int k = 0; k < 2; k++) for (int w = 0; w < 2; w++) for (hipEvent_t e : c->prof->ev[k][w]) hipEventDestroy(e);
@@ -225,6 +228,14 @@ int phip_wait_ll(phip_ctx c, const unsigned long long *ll, int n, unsigned long 
     const unsigned long long bits = (__atomic_load_n(&ll[2 * i], __ATOMIC_RELAXED) & 0xFFFFFFFFull) | (__atomic_load_n(&ll[2 * i + 1], __ATOMIC_RELAXED) << 32);
     memcpy(&out[i], &bits, 8);
   }
+  if (c->h_err) { /* a reduction kernel that gave up waiting for a workgroup's partial result says so here (phip_reduce.h) */
+    const unsigned int e = __atomic_load_n(c->h_err, __ATOMIC_ACQUIRE);
+    if (e) {
+      __atomic_store_n(c->h_err, 0u, __ATOMIC_RELAXED);
+      phip_set_error("%s: a reduction kernel (launch flag %u) gave up waiting for the partial result of one of its workgroups and published NaN; the device is overloaded or a workgroup died", what, e);
+      return PHIP_ERR_LIB;
+    }
+  }
   return 0;
 }
 
@@ -350,7 +361,7 @@ int phip_ticket_open(phip_ctx c, int nvals, int publish, phip_ticket *t, RedCtl 
   const int                slot = (int)(seq % PHIP_RING);
   t->slot = slot; t->nvals = nvals; t->seq = seq;
   ctl->partial = c->d_partials; ctl->pflag = phip_next_pflag(c); ctl->d_out = c->d_ring + (size_t)slot * PHIP_RING_VALS;
-  ctl->kofs = 0; ctl->accumulate = 0; ctl->npub = 0; ctl->h_ll = NULL; ctl->seq = 0;
+  ctl->kofs = 0; ctl->accumulate = 0; ctl->npub = 0; ctl->h_ll = NULL; ctl->seq = 0; ctl->err = c->h_err_dev;
   if (publish) { ctl->h_ll = c->h_ring_dev[slot].ll; ctl->seq = seq; ctl->npub = nvals; }
   return 0;
 }
@@ -364,7 +375,7 @@ int phip_ticket_accumulate(phip_ctx c, const phip_ticket *t, int publish, RedCtl
 {
   PHIP_REQUIRE(ticket_live(c, t), PHIP_ERR_ARG_WRONGSTATE, "phip_ticket_accumulate: the ticket has expired");
   ctl->partial = c->d_partials; ctl->pflag = phip_next_pflag(c); ctl->d_out = c->d_ring + (size_t)t->slot * PHIP_RING_VALS;
-  ctl->kofs = 0; ctl->accumulate = 1; ctl->npub = 0; ctl->h_ll = NULL; ctl->seq = 0;
+  ctl->kofs = 0; ctl->accumulate = 1; ctl->npub = 0; ctl->h_ll = NULL; ctl->seq = 0; ctl->err = c->h_err_dev;
   if (publish) { ctl->h_ll = c->h_ring_dev[t->slot].ll; ctl->seq = t->seq; ctl->npub = t->nvals; }
   return 0;
 }

@@ -2062,9 +2062,9 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
   if (A->sell_on) {
     /* with the fused dot the grid is capped (the tail sums one partial per workgroup).  Measured on 7-point 128^3, CG it/s: cap 1024
        11.32 k, 2048 11.08 k, 4096 11.10 k -- the cost of the fused dot is its tail (partials -> last workgroup -> pinned host slot),
-       not occupancy.  PHIP_SPMV_DOT_GRID overrides (<= PHIP_RED_BLOCKS) */
+       not occupancy.  PHIP_SPMV_DOT_GRID overrides (<= PHIP_RED_RESIDENT: the collector waits for workgroups that must be resident) */
     static const int dot_grid_env = getenv("PHIP_SPMV_DOT_GRID") ? atoi(getenv("PHIP_SPMV_DOT_GRID")) : 0;
-    const int      dot_cap = (dot_grid_env > 0 && dot_grid_env <= PHIP_RED_BLOCKS) ? dot_grid_env : 1024;
+    const int      dot_cap = (dot_grid_env > 0 && dot_grid_env <= PHIP_RED_RESIDENT) ? dot_grid_env : 1024;
     const unsigned grid = DOT ? (unsigned)(A->sell_nslices < dot_cap ? A->sell_nslices : dot_cap) : (unsigned)A->sell_nslices;
     const bool     nt = A->nt_user >= 0 ? A->nt_user != 0 : 9 * A->sell_padded > PHIP_NT_MATRIX_BYTES;
     /* results of 64 MiB and more leave with non-temporal stores: they do not push x out of the caches while the product still
@@ -2166,7 +2166,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
 #undef SELL_LAUNCH
   } else {
     static const int dot_grid_env = getenv("PHIP_SPMV_DOT_GRID") ? atoi(getenv("PHIP_SPMV_DOT_GRID")) : 0;
-    const int      dot_cap = (dot_grid_env > 0 && dot_grid_env <= PHIP_RED_BLOCKS) ? dot_grid_env : 1024;
+    const int      dot_cap = (dot_grid_env > 0 && dot_grid_env <= PHIP_RED_RESIDENT) ? dot_grid_env : 1024;
     const unsigned grid = DOT ? (unsigned)(A->nblocks < dot_cap ? (A->nblocks > 0 ? A->nblocks : 1) : dot_cap) : (unsigned)A->nblocks;
     /* out-of-cache irregular matrices: non-temporal matrix stream (R-MAT scale 22: 546 -> 505 us); PHIP_CSR_NT=0/1 overrides */
     static const int csr_nt_env = getenv("PHIP_CSR_NT") ? atoi(getenv("PHIP_CSR_NT")) : -1;

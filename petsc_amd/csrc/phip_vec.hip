@@ -607,7 +607,7 @@ extern "C" int phip_vec_pointwise_mult_reduce(phip_ctx c, int32_t n, double *d_w
     o.op = EW_PMULT; o.hx = 1; o.hy = 1; o.hz = 0; o.out = d_w; o.x = d_x; o.y = d_y; o.z = NULL; o.a = o.b = o.g = 0.0;
     c->ew_n = 0;
     static const int red_grid_env = getenv("PHIP_EW_RED_GRID") ? atoi(getenv("PHIP_EW_RED_GRID")) : 0;
-    const int        red_grid = (red_grid_env > 0 && red_grid_env <= PHIP_RED_BLOCKS) ? red_grid_env : PHIP_RED_GRID;
+    const int        red_grid = (red_grid_env > 0 && red_grid_env <= PHIP_RED_RESIDENT) ? red_grid_env : PHIP_RED_GRID;
     const dim3       grid(phip_grid_for((int64_t)n / 2 + 1, 4, red_grid));
     static const int cgk_env = getenv("PHIP_CG_UPDATE_KERNEL") ? atoi(getenv("PHIP_CG_UPDATE_KERNEL")) : 1;
     const int        shape = cgk_env ? cg_update_shape(B) : 0;
@@ -678,7 +678,7 @@ static int reduce_launch(phip_ctx c, int kind, int32_t n, const double *d_x, int
   /* pub: publish into that slot / sequence word (a by-product ticket) instead of the context's blocking-call slot */
   const int grid = reduce_grid(n);
   RedCtl    ctl;
-  ctl.partial = c->d_partials; ctl.pflag = 0; ctl.d_out = d_out; ctl.h_ll = NULL; ctl.seq = 0; ctl.npub = 0; ctl.kofs = 0; ctl.accumulate = 0;
+  ctl.partial = c->d_partials; ctl.pflag = 0; ctl.d_out = d_out; ctl.h_ll = NULL; ctl.seq = 0; ctl.npub = 0; ctl.kofs = 0; ctl.accumulate = 0; ctl.err = c->h_err_dev;
   if (kind == 0) {
     PHIP_REQUIRE(nv >= 0 && nv <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_vec_reduce_local: nv=%d (max %d)", nv, PHIP_MAX_MVEC);
     PHIP_REQUIRE(h_dy || !nv, PHIP_ERR_ARG_NULL, "phip_vec_reduce_local: null vector list");

@@ -30,6 +30,12 @@ def main():
     A.mult(x, y)
     yref = op.mult(xg)
     assert np.abs(y.array() - yref[rs:re]).max() <= 1e-12 * np.abs(yref).max()
+    for k in range(25):   # consecutive exchanges through one plan: buffers and signals are reused, nothing may be overtaken
+        x.scale(-1.5 if k % 2 else 0.5)
+        xg = xg * (-1.5 if k % 2 else 0.5)
+        A.mult(x, y)
+        yk = op.mult(xg)
+        assert np.abs(y.array() - yk[rs:re]).max() <= 1e-12 * np.abs(yk).max(), k
     A.mult_transpose(x, y)
     tref = op.mult_transpose(xg)
     assert np.abs(y.array() - tref[rs:re]).max() <= 1e-12 * np.abs(tref).max()
@@ -57,6 +63,12 @@ def main():
         assert abs(res["its"] - ref["its"]) <= 1 and res["reason"] == ref["reason"], (res, ref["its"])
         assert np.abs(sol.array() - ref["x"][rs:re]).max() <= 1e-8
         ksp.destroy(); sol.destroy()
+    import ctypes as C
+    from petsc_amd import capi
+    cnt = C.c_ulonglong()
+    capi.load().phip_halo_ipc_count(C.byref(cnt))
+    want_ipc = os.environ.get("PHIP_HALO_IPC", "0") == "1" and backend in ("shm", "rccl")
+    assert (cnt.value > 30) == want_ipc, "peer-write exchanges: %d, PHIP_HALO_IPC=%s" % (cnt.value, os.environ.get("PHIP_HALO_IPC"))
     comm.finalize()
     print("mp ok rank %d" % r)
 

@@ -815,15 +815,16 @@ def test_byproduct_cache(orc, size):
             assert abs(res[key, on] - val) <= 1e-12 * max(abs(val), 1.0), (key, on, res[key, on], val)
 
 
-@pytest.mark.parametrize("n", [2, 3])
-def test_multiprocess_shared_gpu(n):
+@pytest.mark.parametrize("n,ipc", [(2, 0), (3, 0), (2, 1), (3, 1)])
+def test_multiprocess_shared_gpu(n, ipc):
     """One process per rank (as under torch.distributed.run), all on GPU 0, joined by the "shm" backend: products, transposed products,
-    reductions through the cross-process shared-memory ring, GMRES and CG against the oracle."""
+    reductions through the cross-process shared-memory ring, GMRES and CG against the oracle.  ipc: the forward ghost exchange as
+    peer writes (PHIP_HALO_IPC=1: hipIpc-mapped receive buffers, flag and acknowledgement words) instead of staging through the host."""
     import subprocess
     import sys
     key = os.urandom(128).hex()
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, PHIP_HOST_RING_TIMEOUT="60")
+    env = dict(os.environ, PHIP_HOST_RING_TIMEOUT="60", PHIP_HALO_IPC=str(ipc))
     procs = [subprocess.Popen([sys.executable, os.path.join(here, "_gpu_mp_worker.py"), key, str(n), str(r)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(n)]
     outs = []
