@@ -775,16 +775,18 @@ __device__ __forceinline__ void dmg_step(double (&s)[4], const double (&w)[DM4_W
                  [m2] "s"(mw.w[2]), [m3] "s"(mw.w[3]));
 }
 
-/* spmv_dmask4_kernel without its scalar overhead.  Its counters show 673 scalar against 389 vector instructions per wave (finding the
-   pairs by walking bit sets, table reads with v_readlane, a three-way dispatch on the pair's place in the window, a test and a select
-   per row and pair): the scalar unit, shared by the four SIMDs of a CU, was busy throughout.  Here a group is one 64-byte descriptor
-   fetched with one scalar load, one group ahead; the places of the window are compile-time; the masks come TRANSPOSED, per wave and
-   pair one 64-bit word for each of the lane's four rows (tmask), fetched by scalar loads and used as execution masks; a pair every
-   row holds runs through the same code with full words.  27-point 256^3: 116 -> 91 us; what is left is the vector L1 (one access a
-   clock for the whole launch, TCP_TOTAL_CACHE_ACCESSES) with the waves waiting on it two thirds of their time.  Tried on top of this
-   and slower, all bit-exact: two windows in flight (97 us), contiguous lanes with pairs of rows (91 us), the upper half of the window
-   from the next lane through the lane-shift network with aligned loads, 252 or 248 rows a wave (106 / 112 us: fewer L1 accesses,
-   but 65 % more L2 misses).  The same sums in the same order as spmv_dmask4_kernel: the same bits.
+/* spmv_dmask4_kernel without its instruction overhead.  Its counters (profiles/r02_pmc_spmv_dmask4.json, 27-point 256^3) show 858 vector
+   and 670 scalar instructions per wave for 108 multiply-add pairs a lane: finding the pairs by walking bit sets, table reads with
+   v_readlane, a three-way dispatch on the pair's place in the window, a test and a select per row and pair.  Here a group is one
+   64-byte descriptor fetched with one scalar load, one group ahead; the places of the window are compile-time; the masks come
+   TRANSPOSED, per wave and pair one 64-bit word for each of the lane's four rows (tmask), fetched by scalar loads and used as
+   execution masks; a pair every row holds runs through the same code with full words: 297 vector, 476 scalar instructions and 80
+   scalar loads per wave (profiles/r02_pmc_spmv_dmaskg.json), 27-point 256^3 116 -> 90 us.  What is left is the vector L1: one access
+   a clock and CU for the whole launch (TCP_TOTAL_CACHE_ACCESSES 53.7 M = 210 k per CU in 222 k clocks), the waves waiting on memory
+   half of their time.  Tried on top of this and slower, all bit-exact: two windows in flight (97 us), contiguous lanes with pairs
+   of rows (91 us), the upper half of the window from the next lane through the lane-shift network (v_mov_b32 wave_shl:1) with
+   16-byte aligned loads and 252 or 248 rows a wave (106 / 112 us: a quarter fewer L1 accesses, but 65 % more L2 misses), eight rows
+   a lane (198 us).  The same sums in the same order as spmv_dmask4_kernel: the same bits.
    dmin / dmax: smallest and largest diagonal of the table: a wave all of whose windows stay inside x (all but the first and last few)
    takes the loop without range tests. */
 template <bool DOT, bool ADD>
