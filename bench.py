@@ -23,7 +23,7 @@ legs     (N = 1, rank 0): the other single-GPU measurements the metric names --
                          Infinity Cache, which the leg says
            lap7_256_var  7-point 256^3 with per-entry perturbed values (what a variable-coefficient / FEM assembly gives): no value
                          dictionary applies, the matrix streams 9 B/nz (SELL-dict) from HBM, 1.5 GB per launch, far outside the caches
-           lap7_256_csr  the same matrix through the general CSR row-block kernel (12 B/nz, any matrix)
+                         ("roofline"), and the same matrix through the general CSR row-block kernel ("roofline_csr", 12 B/nz, any matrix)
 cpu_baseline = the oracle (C restatement of the reference loops, -O3 -march=native) on the same system: 16 row blocks / threads as
            MATMPIAIJ would run it on the host's CPU share, and one core (MATSEQAIJ); rank 0 at N = 1 only, bounded sample.
 Timing: hipEvents on the library's compute stream.  avg = K launches back to back between two events (best of 3); p10/p50/p90 = the
