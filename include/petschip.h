@@ -321,11 +321,13 @@ int phip_comm_barrier(phip_comm comm);
 int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_procs, const int32_t *to_starts, const int32_t *to_indices,
                      int32_t from_n, const int32_t *from_procs, const int32_t *from_starts, phip_halo *halo);
 int phip_halo_destroy(phip_halo halo);
-/* PHIP_HALO_IPC=1 (set alike on every rank before phip_halo_create; backends "rccl" and "shm", ranks of one node): the forward exchange
- * as PEER WRITES -- the ranks map each other's receive buffers (hipIpcGetMemHandle / hipIpcOpenMemHandle), the pack kernel of
- * phip_halo_begin stores x[to_indices] straight into them and raises a flag word there; phip_halo_end launches one kernel that waits
- * for the flags, copies to lvec and acknowledges.  No send/receive kernels, no second stream.  Off by default: it runs between
- * processes sharing one GPU (tests) but has not yet run between GPUs.  phip_halo_ipc_count: exchanges this process made that way. */
+/* The forward exchange as PEER WRITES: the ranks map each other's receive buffers (hipIpcGetMemHandle / hipIpcOpenMemHandle), the pack
+ * kernel of phip_halo_begin stores x[to_indices] straight into them and raises a flag word there; phip_halo_end launches one kernel that
+ * waits for the flags, copies to lvec and acknowledges.  No send/receive kernels, no second stream.  PHIP_HALO_IPC (alike on every rank,
+ * read by phip_halo_create): unset -- tried with the "rccl" backend when all ranks share the node, and kept only if three trial exchanges
+ * deliver on every rank what was sent (otherwise the grouped ncclSend/ncclRecv path, silently; PHIP_VERBOSE=1 says why); 1 -- required
+ * ("rccl" and "shm" backends), an error if unavailable; 0 -- never.  It has run between processes sharing one GPU (tests), not yet
+ * between GPUs.  phip_halo_ipc_count: exchanges this process made that way (trial ones included). */
 int phip_halo_ipc_count(unsigned long long *n);
 int phip_halo_begin(phip_halo halo, const double *d_x_local, double *d_lvec);
 int phip_halo_end(phip_halo halo);

@@ -175,6 +175,7 @@ struct phip_halo_s {
   unsigned long long **d_peer_flag;  /* [to_n] my flag word in neighbour i's ipc_sync */
   unsigned long long **d_peer_ack;   /* [from_n] my acknowledgement word in neighbour j's ipc_sync */
   std::vector<void *>  ipc_opened;   /* mappings to close */
+  const char          *ipc_why;      /* why the path is not in use although it was asked for (NULL: it is, or it was not asked for) */
 };
 
 /* ---- host reduction ring: attach / detach / one round -------------------------------------------------------------------- */
@@ -727,11 +728,19 @@ static int halo_ipc_setup(phip_halo h)
 {
   phip_comm c = h->comm;
   phip_ctx  ctx = c->ctx;
-  PHIP_REQUIRE(h->to_n <= PHIP_THREADS && h->from_n <= PHIP_THREADS, PHIP_ERR_SUP, "peer-write halo: more than %d neighbours", PHIP_THREADS);
+  h->ipc_why = NULL;
+  { /* more neighbours than a workgroup has threads, anywhere: not this way (decided together) */
+    int32_t              mine = h->to_n > PHIP_THREADS || h->from_n > PHIP_THREADS;
+    std::vector<int32_t> every((size_t)c->size);
+    int                  rc0 = phip_comm_allgather_host(c, &mine, every.data(), sizeof(int32_t));
+    if (rc0) return rc0;
+    for (int p = 0; p < c->size; p++) if (every[(size_t)p]) { h->ipc_why = "a rank has more than 256 neighbours"; return 0; }
+  }
   const size_t nsync = (size_t)h->from_n + (size_t)h->to_n + 2;
   PHIP_CHECK_HIP(hipMalloc((void **)&h->ipc_recv, sizeof(double) * ((size_t)h->nrecv + 2)));
   PHIP_CHECK_HIP(hipMalloc((void **)&h->ipc_sync, sizeof(unsigned long long) * nsync));
   PHIP_CHECK_HIP(hipMemset(h->ipc_sync, 0, sizeof(unsigned long long) * nsync));
+  PHIP_CHECK_HIP(hipDeviceSynchronize()); /* hipMemset of device memory does not wait: the words must be zero before a neighbour can store into them */
   struct Head { hipIpcMemHandle_t recv, sync; int32_t from_n, to_n, ok, pad; };
   std::vector<unsigned char> rec(sizeof(Head) + sizeof(int32_t) * ((size_t)2 * h->from_n + 1 + (size_t)h->to_n));
   Head                       hd;
@@ -749,7 +758,7 @@ static int halo_ipc_setup(phip_halo h)
   if (rc) return rc;
   int allok = 1;
   for (int p = 0; p < c->size; p++) { Head q; memcpy(&q, all[(size_t)p].data(), sizeof(q)); allok = allok && q.ok; }
-  PHIP_REQUIRE(allok, PHIP_ERR_LIB, "peer-write halo: hipIpcGetMemHandle failed on some rank");
+  if (!allok) { h->ipc_why = "hipIpcGetMemHandle failed on some rank"; return 0; }
   std::vector<double *>             peer_recv((size_t)h->to_n + 1, NULL);
   std::vector<unsigned long long *> peer_flag((size_t)h->to_n + 1, NULL), peer_ack((size_t)h->from_n + 1, NULL);
   std::vector<void *>               recv_of((size_t)c->size, NULL), sync_of((size_t)c->size, NULL);
@@ -757,9 +766,9 @@ static int halo_ipc_setup(phip_halo h)
     if (sync_of[(size_t)p]) return 0;
     Head q;
     memcpy(&q, all[(size_t)p].data(), sizeof(q));
-    PHIP_CHECK_HIP(hipIpcOpenMemHandle(&recv_of[(size_t)p], q.recv, hipIpcMemLazyEnablePeerAccess));
+    if (hipIpcOpenMemHandle(&recv_of[(size_t)p], q.recv, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return 1; }
     h->ipc_opened.push_back(recv_of[(size_t)p]);
-    PHIP_CHECK_HIP(hipIpcOpenMemHandle(&sync_of[(size_t)p], q.sync, hipIpcMemLazyEnablePeerAccess));
+    if (hipIpcOpenMemHandle(&sync_of[(size_t)p], q.sync, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); sync_of[(size_t)p] = NULL; return 1; }
     h->ipc_opened.push_back(sync_of[(size_t)p]);
     return 0;
   };
@@ -791,7 +800,8 @@ static int halo_ipc_setup(phip_halo h)
   std::vector<int32_t> bads((size_t)c->size);
   int32_t              mybad = bad;
   if ((rc = phip_comm_allgather_host(c, &mybad, bads.data(), sizeof(int32_t)))) return rc;
-  for (int p = 0; p < c->size; p++) PHIP_REQUIRE(!bads[(size_t)p], PHIP_ERR_LIB, "peer-write halo: rank %d could not map its neighbours (%s)", p, bads[(size_t)p] == 1 ? "hipIpcOpenMemHandle failed" : "the plans of two neighbours do not match");
+  for (int p = 0; p < c->size; p++)
+    if (bads[(size_t)p]) { h->ipc_why = bads[(size_t)p] == 1 ? "hipIpcOpenMemHandle failed on some rank" : "the plans of two neighbours do not match"; return 0; }
   std::vector<int32_t> seg((size_t)h->nsend + 1, 0);
   for (int i = 0; i < h->to_n; i++) for (int32_t k = h->to_starts[(size_t)i]; k < h->to_starts[(size_t)i + 1]; k++) seg[(size_t)k] = i;
   PHIP_CHECK_HIP(hipMalloc((void **)&h->d_send_seg, sizeof(int32_t) * seg.size()));
@@ -805,8 +815,43 @@ static int halo_ipc_setup(phip_halo h)
   PHIP_CHECK_HIP(hipMemcpy(h->d_peer_flag, peer_flag.data(), sizeof(void *) * peer_flag.size(), hipMemcpyHostToDevice));
   PHIP_CHECK_HIP(hipMemcpy(h->d_peer_ack, peer_ack.data(), sizeof(void *) * peer_ack.size(), hipMemcpyHostToDevice));
   h->ipc_seq = 0;
+  if ((rc = phip_comm_barrier(c))) return rc; /* nobody stores into a buffer before its owner has zeroed the sync words and everyone has mapped */
+  /* Three trial exchanges before anything relies on the path: every rank sends a constant of its own per round (1000 rank + round), so
+     a receiver knows what each segment must hold without knowing its neighbour's indices.  Exercises mapping, flags, acknowledgements
+     and the reuse of the buffers; the ranks then agree on the verdict. */
+  int32_t maxidx = 0;
+  {
+    std::vector<int32_t> idx((size_t)h->nsend + 1);
+    if (h->nsend) PHIP_CHECK_HIP(hipMemcpy(idx.data(), h->d_to_indices, sizeof(int32_t) * (size_t)h->nsend, hipMemcpyDeviceToHost));
+    for (int32_t k = 0; k < h->nsend; k++) maxidx = std::max(maxidx, idx[(size_t)k]);
+  }
+  double *tx = NULL, *tl = NULL;
+  PHIP_CHECK_HIP(hipMalloc((void **)&tx, sizeof(double) * ((size_t)maxidx + 2)));
+  PHIP_CHECK_HIP(hipMalloc((void **)&tl, sizeof(double) * ((size_t)h->nrecv + 2)));
+  std::vector<double> hx((size_t)maxidx + 1), hl((size_t)h->nrecv + 1);
+  int32_t             good = 1;
   h->ipc_on = 1;
-  return phip_comm_barrier(c); /* nobody stores into a buffer before its owner has zeroed the sync words and everyone has mapped */
+  for (int round = 1; round <= 3; round++) {
+    std::fill(hx.begin(), hx.end(), 1000.0 * c->rank + round);
+    PHIP_CHECK_HIP(hipMemcpy(tx, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
+    PHIP_CHECK_HIP(hipMemsetAsync(tl, 0xff, sizeof(double) * ((size_t)h->nrecv + 1), ctx->stream)); /* on the stream of the exchange: it does not wait for the null stream */
+    int r1 = phip_halo_begin(h, tx, tl);
+    int r2 = r1 ? r1 : phip_halo_end(h);
+    if (r2 || hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); good = 0; }
+    else if (h->nrecv) {
+      PHIP_CHECK_HIP(hipMemcpy(hl.data(), tl, sizeof(double) * (size_t)h->nrecv, hipMemcpyDeviceToHost));
+      for (int j = 0; j < h->from_n && good; j++)
+        for (int32_t k = h->from_starts[(size_t)j]; k < h->from_starts[(size_t)j + 1]; k++)
+          if (hl[(size_t)k] != 1000.0 * h->from_procs[(size_t)j] + round) { good = 0; break; }
+    }
+    if (ctx->h_err && __atomic_load_n(ctx->h_err, __ATOMIC_ACQUIRE)) { __atomic_store_n(ctx->h_err, 0u, __ATOMIC_RELAXED); good = 0; }
+  }
+  h->lvec = NULL;
+  hipFree(tx); hipFree(tl);
+  std::vector<int32_t> goods((size_t)c->size);
+  if ((rc = phip_comm_allgather_host(c, &good, goods.data(), sizeof(int32_t)))) return rc;
+  for (int p = 0; p < c->size; p++) if (!goods[(size_t)p]) { h->ipc_on = 0; h->ipc_why = "the trial exchanges did not deliver what was sent"; }
+  return 0;
 }
 
 extern "C" int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_procs, const int32_t *to_starts, const int32_t *to_indices,
@@ -828,7 +873,7 @@ extern "C" int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_
   phip_ctx ctx = comm->ctx;
   h->d_to_indices = NULL; h->d_sendbuf = NULL; h->lvec = NULL;
   h->ntgt = 0; h->d_tgt = h->d_tptr = h->d_tpos = NULL; h->rev_lvec = NULL;
-  h->ipc_on = 0; h->ipc_seq = 0; h->ipc_recv = NULL; h->ipc_sync = NULL; h->d_send_seg = NULL; h->d_to_starts = NULL; h->d_peer_recv = NULL; h->d_peer_flag = NULL; h->d_peer_ack = NULL;
+  h->ipc_why = NULL; h->ipc_on = 0; h->ipc_seq = 0; h->ipc_recv = NULL; h->ipc_sync = NULL; h->d_send_seg = NULL; h->d_to_starts = NULL; h->d_peer_recv = NULL; h->d_peer_flag = NULL; h->d_peer_ack = NULL;
   if (ctx->device < 0) { *out = h; return 0; } /* planning-only: the plan stays on the host */
   PHIP_CHECK_HIP(hipSetDevice(ctx->device));
   PHIP_CHECK_HIP(hipMalloc((void **)&h->d_to_indices, sizeof(int32_t) * ((size_t)h->nsend + 4)));
@@ -865,10 +910,20 @@ extern "C" int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_
   }
   PHIP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
   PHIP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
-  /* PHIP_HALO_IPC=1: the peer-write exchange between the processes of one node (backends rccl and shm); every rank must set it alike */
-  if (comm->size > 1 && (comm->backend == BACKEND_RCCL || comm->backend == BACKEND_SHM) && getenv("PHIP_HALO_IPC") && atoi(getenv("PHIP_HALO_IPC"))) {
-    int rc = halo_ipc_setup(h);
-    if (rc) return rc;
+  /* PHIP_HALO_IPC (every rank alike): 1 = the peer-write exchange between the processes of one node (backends rccl and shm), an error if
+     it cannot be set up; 0 = never; unset = try it with the rccl backend when all ranks share the node (the host ring is attached) and
+     keep it only if the trial exchanges pass on every rank, else the grouped ncclSend/ncclRecv path as before */
+  {
+    const char *e = getenv("PHIP_HALO_IPC");
+    const int   mode = e ? (atoi(e) ? 1 : 0) : -1;
+    const bool  can = comm->size > 1 && (comm->backend == BACKEND_RCCL || comm->backend == BACKEND_SHM);
+    const bool  want = can && (mode == 1 || (mode == -1 && comm->backend == BACKEND_RCCL && comm->hr.slots));
+    if (want) {
+      int rc = halo_ipc_setup(h);
+      if (rc) return rc;
+      if (!h->ipc_on && mode == 1) PHIP_REQUIRE(0, PHIP_ERR_LIB, "phip_halo_create: PHIP_HALO_IPC=1 but the peer-write exchange is not available: %s", h->ipc_why ? h->ipc_why : "?");
+      if (!h->ipc_on && getenv("PHIP_VERBOSE")) fprintf(stderr, "[phip] rank %d: peer-write ghost exchange not used (%s); RCCL send/recv instead\n", comm->rank, h->ipc_why ? h->ipc_why : "?");
+    }
   }
   *out = h;
   return 0;

@@ -840,12 +840,13 @@ def test_multiprocess_shared_gpu(n, ipc):
         assert p.returncode == 0 and "mp ok rank %d" % r in o, o[-3000:]
 
 
-@pytest.mark.parametrize("device_allreduce", [False, True])
-def test_multiprocess_rccl(device_allreduce):
+@pytest.mark.parametrize("device_allreduce,halo", [(False, "0"), (True, "0"), (False, "1"), (False, None)])
+def test_multiprocess_rccl(device_allreduce, halo):
     """The route bench.py --gpus N takes: one process and one GPU per rank, backend "rccl" -- set-up handshake (ncclAllGather, grouped
     send/recv all-to-all), host-name check and shared-memory ring attach, the grouped ncclSend/ncclRecv ghost exchange forward and in
     reverse with ADD, reductions through the host ring or (PETSCHIP_DEVICE_ALLREDUCE=1) ncclAllReduce -- against the oracle.
-    Needs two GPUs: skipped on a one-GPU box (RCCL refuses two ranks on one device)."""
+    halo: the ghost exchange as grouped ncclSend/ncclRecv ("0"), as peer writes ("1") or as the library chooses (None: peer writes if
+    its trial exchanges pass).  Needs two GPUs: skipped on a one-GPU box (RCCL refuses two ranks on one device)."""
     import subprocess
     import sys
     import ctypes as C
@@ -862,6 +863,9 @@ def test_multiprocess_rccl(device_allreduce):
         env["PETSCHIP_DEVICE_ALLREDUCE"] = "1"
     else:
         env.pop("PETSCHIP_DEVICE_ALLREDUCE", None)
+    env.pop("PHIP_HALO_IPC", None)          # halo: "0" grouped ncclSend/ncclRecv, "1" peer writes, None the library's own choice
+    if halo is not None:
+        env["PHIP_HALO_IPC"] = halo
     procs = [subprocess.Popen([sys.executable, os.path.join(here, "_gpu_mp_worker.py"), key, str(n), str(r), "rccl", str(r)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(n)]
     outs = []
