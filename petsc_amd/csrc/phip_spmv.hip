@@ -138,6 +138,9 @@ struct phip_mat_s {
   int       dm_dmin, dm_dmax; /* smallest / largest diagonal of the pair table */
   void     *d_gdesc;  /* [dm_ndesc + 3] DmGroup: the groups of spmv_dmaskg_kernel (at most one pair per place of the window) */
   int       dm_ndesc;
+  int32_t  *d_segs;   /* [dm_nseg][4] segments of spmv_dmasks_kernel: {first diagonal (even), entries of x to stage, first group, one behind the last} */
+  int       dm_nseg, dm_seg_maxlen, dm_smin, dm_smax; /* dm_nseg = 0: the staged kernel does not apply */
+  double    dm_l1_ratio; /* entries of x per row requested from the L1 by spmv_dmaskg_kernel / by the staged kernel */
   double   *d_dotpart; /* [4 S] the fused dot's partial sum of each wave (spmv_dmask_kernel<DOT>, summed by dot_wave_partials_kernel) */
   int32_t  *d_dmoffs; /* [32] */
   double   *d_dmvals; /* [32] */
@@ -783,10 +786,11 @@ __device__ __forceinline__ void dmg_step(double (&s)[4], const double (&w)[DM4_W
    execution masks; a pair every row holds runs through the same code with full words: 297 vector, 476 scalar instructions and 80
    scalar loads per wave (profiles/r02_pmc_spmv_dmaskg.json), 27-point 256^3 116 -> 90 us.  What is left is the vector L1: one access
    a clock and CU for the whole launch (TCP_TOTAL_CACHE_ACCESSES 53.7 M = 210 k per CU in 222 k clocks), the waves waiting on memory
-   half of their time.  Tried on top of this and slower, all bit-exact: two windows in flight (97 us), contiguous lanes with pairs
-   of rows (91 us), the upper half of the window from the next lane through the lane-shift network (v_mov_b32 wave_shl:1) with
-   16-byte aligned loads and 252 or 248 rows a wave (106 / 112 us: a quarter fewer L1 accesses, but 65 % more L2 misses), eight rows
-   a lane (198 us).  The same sums in the same order as spmv_dmask4_kernel: the same bits.
+   half of their time.  Tried on top of this and no faster, all bit-exact: two windows in flight (130 us: more lines in flight than
+   the L1 holds, its hits on the windows' overlaps are what the kernel lives on), contiguous lanes with pairs of rows (91 us), entries
+   4 and 5 of the window from the next lane through the lane-shift network (v_mov_b32 wave_shl:1; 93 us with a third fewer bytes
+   requested), the same with 16-byte aligned loads and 252 or 248 rows a wave (106 / 112 us: 65 % more L2 misses), eight rows a
+   lane (198 us), the windows staged in LDS (spmv_dmasks_kernel below: 108 us).  The same sums in the same order as spmv_dmask4_kernel: the same bits.
    dmin / dmax: smallest and largest diagonal of the table: a wave all of whose windows stay inside x (all but the first and last few)
    takes the loop without range tests. */
 template <bool DOT, bool ADD>
@@ -846,6 +850,127 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmaskg_kernel(int32_t m, in
     }
   };
   if (w0 + dmin >= 0 && w0 + DMG_WAVE_ROWS - 1 + dmax + (DM4_SPAN - 1) < (int64_t)n) run(std::true_type());
+  else run(std::false_type());
+  if (nact >= DM4_ROWS) {
+    st_result2(yout + r0, s[0], s[1], nty);
+    st_result2(yout + r0 + 2, s[2], s[3], nty);
+  } else {
+#pragma unroll
+    for (int i = 0; i < DM4_ROWS; i++) if (i < nact) yout[r0 + i] = s[i];
+  }
+  if (DOT) { /* one partial per wave, stored and forgotten (dot_wave_partials_kernel sums them); the weights are requested only now */
+    double dv[DM4_ROWS] = {0.0, 0.0, 0.0, 0.0};
+    if (nact >= DM4_ROWS) {
+      const phip_v2d_u a = *reinterpret_cast<const phip_v2d_u *>(dotv + r0), b = *reinterpret_cast<const phip_v2d_u *>(dotv + r0 + 2);
+      dv[0] = a.x; dv[1] = a.y; dv[2] = b.x; dv[3] = b.y;
+    } else {
+#pragma unroll
+      for (int i = 0; i < DM4_ROWS; i++) if (i < nact) dv[i] = dotv[r0 + i];
+    }
+    double dacc = 0.0;
+#pragma unroll
+    for (int i = 0; i < DM4_ROWS; i++) if (i < nact) dacc += dv[i] * (ADD ? s[i] - y0[i] : s[i]); /* MultAdd: the increment A x, not z */
+    dacc = wave_sum(dacc);
+    if ((t & 63) == 0) wavepart[(size_t)blockIdx.x * (PHIP_THREADS / 64) + (t >> 6)] = dacc;
+  }
+}
+
+/* spmv_dmaskg_kernel with the windows of x STAGED IN LDS.  What bounds spmv_dmaskg_kernel is the vector L1 (108 bytes requested per
+   row for 27 points): every group fetches its own window, six entries for four rows, although the groups of one plane of a stencil
+   (diagonals D, D + nx, D + 2 nx) walk over the same entries of x.  Here the groups are gathered into SEGMENTS of neighbouring
+   diagonals (host: setup_dmask); a workgroup (1024 rows) fetches the stretch of x a segment needs ONCE, coalesced and 16-byte aligned
+   -- 1024 + span entries, 12 KB for a plane of the 27-point 256^3 stencil: 36 bytes per row through the L1 for the three planes
+   instead of 108 -- and every lane takes its windows from LDS (128 bytes a clock).  The next segment's stretch is requested into
+   registers before the sums of this one begin.  Same descriptors, same transposed masks as execution masks, same sums in the same
+   order: the same bits.  MEASURED SLOWER, hence only behind phip_set_dmask_kernel(6): 27-point 256^3 108 us against 90 us
+   (132 us before the stretch was padded against bank conflicts): L1 accesses fall from 53.7 M to 16.4 M per launch as intended,
+   but a wave now issues 511 vector + 611 scalar + 70 LDS instructions (index arithmetic of the padded layout, barriers, staging)
+   against 297 + 476, and that is what the time follows (profiles/r02_pmc_spmv_dmasks.json).  smin / smax: first entry / one behind the last entry any segment touches relative to the workgroup's first
+   row: workgroups whose stretches stay inside x stage without range tests. */
+#define DMS_STAGE 4 /* 16-byte loads per thread and segment: stretches of up to 2048 entries */
+/* entry e of a stretch lives at LDS index e + e / 32: the lanes' windows start four entries (eight banks) apart, so without the padding
+   lanes l, l + 8, l + 16, l + 24 of a half-wave meet in the same banks (measured: 132 us against 90 us for the unstaged kernel) */
+#define DMS_PAD(e) ((e) + ((e) >> 5))
+template <bool DOT, bool ADD>
+__global__ __launch_bounds__(PHIP_THREADS) void spmv_dmasks_kernel(int32_t m, int32_t n, const DmWords *__restrict__ tmask, const phip_u32x16 *__restrict__ gdesc,
+                                                                   const int4 *__restrict__ segs, int nseg, int smin, int smax, const double *__restrict__ x,
+                                                                   const double *__restrict__ yin, double *__restrict__ yout, const double *__restrict__ dotv,
+                                                                   double *__restrict__ wavepart, int nty)
+{
+#pragma clang fp contract(off)
+  extern __shared__ double lx[];
+  const int      t = threadIdx.x;
+  const int      wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (PHIP_THREADS / 64) + (t >> 6));
+  const int64_t  R0 = (int64_t)blockIdx.x * DMG_WG_ROWS;
+  const int      r0 = (int)R0 + DM4_ROWS * t;
+  const int      nact = m - r0; /* rows r0 .. r0 + 3 exist while i < nact */
+  double         y0[DM4_ROWS] = {0.0, 0.0, 0.0, 0.0}, s[DM4_ROWS];
+  if (ADD) {
+    if (nact >= DM4_ROWS) {
+      const phip_v2d_u a = *reinterpret_cast<const phip_v2d_u *>(yin + r0), b = *reinterpret_cast<const phip_v2d_u *>(yin + r0 + 2);
+      y0[0] = a.x; y0[1] = a.y; y0[2] = b.x; y0[3] = b.y;
+    } else {
+#pragma unroll
+      for (int i = 0; i < DM4_ROWS; i++) if (i < nact) y0[i] = yin[r0 + i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DM4_ROWS; i++) s[i] = y0[i];
+  const DmWords *tmw = tmask + (size_t)wave * DMG_WORDS;
+  auto run = [&](auto fastc) {
+    constexpr bool FAST = decltype(fastc)::value;
+    phip_v2d_u st[DMS_STAGE];
+    /* the stretch of segment sg, two entries a thread and load, into registers */
+    auto fetch = [&](const int4 sg) {
+#pragma unroll
+      for (int k = 0; k < DMS_STAGE; k++) {
+        const int e = 2 * (t + PHIP_THREADS * k);
+        if (e < sg.y) {
+          if (FAST) st[k] = *reinterpret_cast<const phip_v2d_u *>(x + (R0 + sg.x + e));
+          else { /* clamped: an entry outside x is never used by a row's own pairs */
+            int64_t i0 = R0 + sg.x + e, i1 = i0 + 1;
+            i0 = i0 < 0 ? 0 : (i0 >= (int64_t)n ? (int64_t)n - 1 : i0);
+            i1 = i1 < 0 ? 0 : (i1 >= (int64_t)n ? (int64_t)n - 1 : i1);
+            st[k].x = x[i0]; st[k].y = x[i1];
+          }
+        }
+      }
+    };
+    auto put = [&](const int4 sg) {
+#pragma unroll
+      for (int k = 0; k < DMS_STAGE; k++) {
+        const int e = 2 * (t + PHIP_THREADS * k);
+        if (e < sg.y) { const int f = DMS_PAD(e); lx[f] = st[k].x; lx[f + 1] = st[k].y; } /* e is even: e and e + 1 share their padding */
+      }
+    };
+    int4    sg = segs[0];
+    DmGroup nxt = __builtin_bit_cast(DmGroup, gdesc[0]);
+    fetch(sg);
+    for (int si = 0; si < nseg; si++) {
+      put(sg);
+      __syncthreads();
+      const int4 cur = sg;
+      if (si + 1 < nseg) { sg = segs[si + 1]; fetch(sg); }
+      for (int g = cur.z; g < cur.w; g++) {
+        const DmGroup d = nxt;
+        nxt = __builtin_bit_cast(DmGroup, gdesc[g + 1]); /* the table has a spare descriptor behind the last group */
+        const DmWords m0 = tmw[d.q[0]], m1 = tmw[d.q[1]], m2 = tmw[d.q[2]];
+        asm volatile("" ::"s"(m0.w[0]), "s"(m0.w[1]), "s"(m0.w[2]), "s"(m0.w[3]), "s"(m1.w[0]), "s"(m1.w[1]), "s"(m1.w[2]), "s"(m1.w[3]));
+        asm volatile("" ::"s"(m2.w[0]), "s"(m2.w[1]), "s"(m2.w[2]), "s"(m2.w[3]));
+        const int e0 = DM4_ROWS * t + d.pad1[0]; /* pad1[0]: the group's base diagonal relative to its segment's */
+        double    w[DM4_WIN];
+#pragma unroll
+        for (int j = 0; j < DM4_WIN; j++) w[j] = lx[DMS_PAD(e0 + j)];
+        dmg_step<0>(s, w, d.v[0], m0);
+        if (d.span > 1) {
+          dmg_step<1>(s, w, d.v[1], m1);
+          dmg_step<2>(s, w, d.v[2], m2);
+        }
+      }
+      __syncthreads(); /* everybody is done with this stretch before the next one overwrites it */
+    }
+  };
+  if (R0 + smin >= 0 && R0 + smax <= (int64_t)n) run(std::true_type());
   else run(std::false_type());
   if (nact >= DM4_ROWS) {
     st_result2(yout + r0, s[0], s[1], nty);
@@ -1516,8 +1641,8 @@ static void free_pairs(phip_mat A)
 
 static void free_dmask(phip_mat A)
 {
-  if (A->ctx->device >= 0) { hipFree(A->d_rmask); hipFree(A->d_dmoffs); hipFree(A->d_dmvals); hipFree(A->d_dotpart); hipFree(A->d_dmgrp); hipFree(A->d_tmask); hipFree(A->d_gdesc); }
-  A->d_tmask = NULL; A->d_gdesc = NULL; A->dm_ndesc = 0;
+  if (A->ctx->device >= 0) { hipFree(A->d_rmask); hipFree(A->d_dmoffs); hipFree(A->d_dmvals); hipFree(A->d_dotpart); hipFree(A->d_dmgrp); hipFree(A->d_tmask); hipFree(A->d_gdesc); hipFree(A->d_segs); }
+  A->d_tmask = NULL; A->d_gdesc = NULL; A->dm_ndesc = 0; A->d_segs = NULL; A->dm_nseg = 0;
   A->d_rmask = NULL; A->d_dmoffs = NULL; A->d_dmvals = NULL; A->d_dotpart = NULL; A->d_dmgrp = NULL; A->dm_ngroups = 0; A->dm_built = 0; A->dm_on = 0; A->dm_npairs = 0;
 }
 
@@ -1591,6 +1716,27 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
   }
   A->dm_dmin = offs[0]; A->dm_dmax = offs[npairs - 1];
   A->dm_ndesc = ndesc;
+  /* segments of spmv_dmasks_kernel: consecutive groups whose diagonals lie within a stretch of at most 2048 entries for 1024 rows */
+  int32_t segs[DMASK_MAX_PAIRS][4];
+  int     nseg = 0, maxlen = 0, smin = 0, smax = 0;
+  double  direct = 0.0, staged = 0.0;
+  for (int g = 0; g < ndesc;) {
+    const int32_t D0 = gd[g].D & ~1; /* even: the staging loads are 16-byte aligned */
+    int           e = g;
+    int64_t       last = (int64_t)gd[g].D + DM4_SPAN - 1;
+    while (e + 1 < ndesc && (int64_t)gd[e + 1].D + DM4_SPAN - 1 - D0 + DMG_WG_ROWS + 2 <= 2 * PHIP_THREADS * DMS_STAGE) { e++; last = (int64_t)gd[e].D + DM4_SPAN - 1; }
+    const int64_t len64 = (last - D0 + DMG_WG_ROWS + 2) & ~(int64_t)1;
+    if (len64 > 2 * PHIP_THREADS * DMS_STAGE) { nseg = 0; break; } /* a single group cannot exceed it: 1024 + 4 entries */
+    for (int h = g; h <= e; h++) { gd[h].pad1[0] = gd[h].D - D0; direct += gd[h].span > 1 ? 6.0 / 4.0 : 1.0; }
+    segs[nseg][0] = D0; segs[nseg][1] = (int32_t)len64; segs[nseg][2] = g; segs[nseg][3] = e + 1;
+    staged += (double)len64 / DMG_WG_ROWS;
+    if (!nseg || D0 < smin) smin = D0;
+    if (!nseg || D0 + (int32_t)len64 > smax) smax = D0 + (int32_t)len64;
+    if ((int)len64 > maxlen) maxlen = (int)len64;
+    nseg++;
+    g = e + 1;
+  }
+  A->dm_nseg = nseg; A->dm_seg_maxlen = maxlen; A->dm_smin = smin; A->dm_smax = smax; A->dm_l1_ratio = staged > 0.0 ? direct / staged : 0.0;
   /* the transposed masks: one wave = 256 rows, lane l holds the rows 4 l .. 4 l + 3 of them (words 0 .. 3); entry DMASK_MAX_PAIRS of
      a wave stays empty (the places of a window that carry no pair) */
   const size_t nwaves = (((size_t)A->m + DMG_WG_ROWS - 1) / DMG_WG_ROWS) * (PHIP_THREADS / 64);
@@ -1616,6 +1762,7 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
   if (!A->d_rmask) {
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_tmask, sizeof(unsigned long long) * tmask.size()));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_gdesc, sizeof(gd)));
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_segs, sizeof(segs)));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dmgrp, sizeof(grp)));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rmask, sizeof(uint32_t) * rmask.size()));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dmoffs, sizeof(offs)));
@@ -1625,6 +1772,7 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_rmask, rmask.data(), sizeof(uint32_t) * rmask.size(), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_tmask, tmask.data(), sizeof(unsigned long long) * tmask.size(), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_gdesc, gd, sizeof(gd), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_segs, segs, sizeof(segs), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmoffs, offs, sizeof(offs), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmvals, vals, sizeof(vals), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmgrp, grp, sizeof(grp), hipMemcpyHostToDevice, st));
@@ -2119,7 +2267,19 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
          PHIP_DMASK_KERNEL / phip_set_dmask_kernel: 4 or 5 (the group-descriptor kernel) for all sizes */
       if (g_dm_kernel < 0) g_dm_kernel = getenv("PHIP_DMASK_KERNEL") ? atoi(getenv("PHIP_DMASK_KERNEL")) : 0;
       const bool use_g = g_dm_kernel == 5 || (g_dm_kernel != 4 && A->m >= DMG_MIN_ROWS);
-      if (dm_rows_env != 2 && use_g) {
+      /* 6: the same with the windows staged in LDS (spmv_dmasks_kernel); requests dm_l1_ratio times fewer entries from the L1 (27-point:
+         3 x) but measured slower, so never by default */
+      const bool use_s = A->dm_nseg > 0 && g_dm_kernel == 6;
+      if (dm_rows_env != 2 && use_s) {
+        nwg = (A->m + DMG_WG_ROWS - 1) / DMG_WG_ROWS;
+        const size_t lds = sizeof(double) * (size_t)(DMS_PAD(A->dm_seg_maxlen) + 2);
+#define DMS_LAUNCH(ADDv)                                                                                                                                  \
+  hipLaunchKernelGGL((spmv_dmasks_kernel<DOT, ADDv>), dim3((unsigned)nwg), dim3(PHIP_THREADS), lds, st, A->m, A->n, reinterpret_cast<const DmWords *>(A->d_tmask), \
+                     reinterpret_cast<const phip_u32x16 *>(A->d_gdesc), reinterpret_cast<const int4 *>(A->d_segs), A->dm_nseg, A->dm_smin, A->dm_smax, d_x, d_yin, \
+                     d_yout, d_v, part, nty)
+        if (add) DMS_LAUNCH(true); else DMS_LAUNCH(false);
+#undef DMS_LAUNCH
+      } else if (dm_rows_env != 2 && use_g) {
         nwg = (A->m + DMG_WG_ROWS - 1) / DMG_WG_ROWS;
 #define DMG_LAUNCH(ADDv)                                                                                                                                  \
   hipLaunchKernelGGL((spmv_dmaskg_kernel<DOT, ADDv>), dim3((unsigned)nwg), dim3(PHIP_THREADS), 0, st, A->m, A->n, reinterpret_cast<const DmWords *>(A->d_tmask), \
@@ -2451,7 +2611,7 @@ extern "C" int phip_set_setup_threads(int nthreads)
 
 extern "C" int phip_set_dmask_kernel(int kind)
 {
-  PHIP_REQUIRE(kind == 0 || kind == 4 || kind == 5, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_dmask_kernel: %d (0 by size, 4 bit sets per row, 5 group descriptors)", kind);
+  PHIP_REQUIRE(kind == 0 || kind == 4 || kind == 5 || kind == 6, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_dmask_kernel: %d (0 by size, 4 bit sets per row, 5 group descriptors, 6 group descriptors with x staged in LDS)", kind);
   g_dm_kernel = kind;
   return 0;
 }

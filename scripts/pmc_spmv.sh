@@ -19,4 +19,5 @@ pass ta "TA_BUSY_avr TA_TA_BUSY_sum" "$@" || exit 4
 pass grbm "GRBM_GUI_ACTIVE GRBM_COUNT" "$@" || exit 5
 pass tcc "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA_RDREQ_sum" "$@" || exit 6
 pass tcp2 "TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" "$@" || exit 7
+pass lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "$@" || exit 8
 echo pmc done

@@ -346,8 +346,9 @@ def test_value_pair_dictionary(ctx, orc):
                 assert abs(a[0] - b[0]) <= 1e-13 * np.abs(v * on[2]).sum()
             else:
                 np.testing.assert_array_equal(a, b)
-        # both mask kernels (by default the size decides): bit sets per row, and group descriptors with transposed masks
-        for kind in (4, 5):
+        # the mask kernels (by default size and structure decide): bit sets per row; group descriptors with transposed masks; the same
+        # with the windows of x staged in LDS
+        for kind in (4, 5, 6):
             ctx.check(L.phip_set_dmask_kernel(kind))
             ctx.check(L.phip_set_default_diag_mask(2))
             try:
