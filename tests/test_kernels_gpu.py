@@ -745,6 +745,37 @@ def test_norm_inf_nan(ctx):
     ctx.free(dx)
 
 
+def test_reductions_under_foreign_load(ctx):
+    """The single-launch reductions let their last workgroup wait for the partial results of the others (phip_reduce.h: workgroups are
+    dispatched in index order and at most 1024 of them exist, so all are resident).  Here that is exercised while ANOTHER PROCESS keeps
+    the same GPU busy with bandwidth-bound launches: every result must arrive (no error from the fetching call, which a collector
+    that gave up would cause through the context's error word), be finite, and equal the result obtained on the idle device bit for bit."""
+    import subprocess
+    import sys
+    import time
+    here = os.path.dirname(os.path.abspath(__file__))
+    rng = np.random.default_rng(77)
+    sizes = [1, 1000, 300001, 2097153, 8388609]
+    data = {n: (rng.standard_normal(n), rng.standard_normal(n)) for n in sizes}
+    dev = {n: (ctx.to_device(a), ctx.to_device(b)) for n, (a, b) in data.items()}
+    idle = {n: (ctx.dot(n, dx, dy), ctx.norm(n, dx, 1), ctx.norm(n, dx, 3), ctx.mdot(n, dx, [dy, dx, dy])) for n, (dx, dy) in dev.items()}
+    load = subprocess.Popen([sys.executable, os.path.join(here, "_gpu_load_worker.py"), "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        assert "load running" in load.stdout.readline()
+        t0, rounds = time.time(), 0
+        while time.time() - t0 < 2.5:
+            for n, (dx, dy) in dev.items():
+                got = (ctx.dot(n, dx, dy), ctx.norm(n, dx, 1), ctx.norm(n, dx, 3), ctx.mdot(n, dx, [dy, dx, dy]))
+                assert got[0] == idle[n][0] and got[1] == idle[n][1] and got[2] == idle[n][2] and np.array_equal(got[3], idle[n][3]), (n, rounds)
+            rounds += 1
+        assert rounds >= 3
+    finally:
+        out, _ = load.communicate(timeout=60)
+    assert load.returncode == 0 and "load done" in out, out[-2000:]
+    for dx, dy in dev.values():
+        ctx.free(dx); ctx.free(dy)
+
+
 @pytest.mark.parametrize("n", [0, 5, 1003, 300001])
 def test_mdot_maxpy(ctx, orc, n):
     """ex43.c-style: fused VecMDot equals per-vector VecDot; VecMAXPY equals the oracle's grouped sum."""
