@@ -796,13 +796,23 @@ __device__ __forceinline__ void dmg_step(double (&s)[4], const double (&w)[DM4_W
 template <bool DOT, bool ADD>
 __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmaskg_kernel(int32_t m, int32_t n, const DmWords *__restrict__ tmask, const phip_u32x16 *__restrict__ gdesc,
                                                                    int ngroups, int dmin, int dmax, const double *__restrict__ x, const double *__restrict__ yin,
-                                                                   double *__restrict__ yout, const double *__restrict__ dotv, double *__restrict__ wavepart, int nty)
+                                                                   double *__restrict__ yout, const double *__restrict__ dotv, double *__restrict__ wavepart, int nty, int xcdmap)
 {
 #pragma clang fp contract(off)
   const int      t = threadIdx.x;
-  const int      wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (PHIP_THREADS / 64) + (t >> 6));
+  /* workgroups go to the XCDs round robin (b mod 8), and each XCD has an L2 of its own.  PHIP_SPMV_XCD_MAP=1 gives every XCD one
+     contiguous eighth of the rows, so that the stretches of x neighbouring row blocks share are fetched into one L2 instead of two:
+     27-point 256^3 back to back (x and masks in the Infinity Cache) 89.3 -> 84.4 us, but from cold caches -- the product inside KSPCG
+     -- 131 -> 159 us and KSPCG 2862 -> 2796 it/s: eight XCDs streaming eight distant regions of x and y suit the memory worse than all
+     of them sweeping one region together.  Off by default. */
+  int bid = (int)blockIdx.x;
+  if (xcdmap) {
+    const int per = (int)gridDim.x >> 3;
+    if (bid < (per << 3)) bid = (bid & 7) * per + (bid >> 3);
+  }
+  const int      wave = __builtin_amdgcn_readfirstlane(bid * (PHIP_THREADS / 64) + (t >> 6));
   const int64_t  w0 = (int64_t)wave * DMG_WAVE_ROWS; /* first row of this wave */
-  const int      r0 = (int)blockIdx.x * DMG_WG_ROWS + DM4_ROWS * t;
+  const int      r0 = bid * DMG_WG_ROWS + DM4_ROWS * t;
   const int      nact = m - r0; /* rows r0 .. r0 + 3 exist while i < nact */
   double         y0[DM4_ROWS] = {0.0, 0.0, 0.0, 0.0}, s[DM4_ROWS];
   if (ADD) {
@@ -871,7 +881,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmaskg_kernel(int32_t m, in
 #pragma unroll
     for (int i = 0; i < DM4_ROWS; i++) if (i < nact) dacc += dv[i] * (ADD ? s[i] - y0[i] : s[i]); /* MultAdd: the increment A x, not z */
     dacc = wave_sum(dacc);
-    if ((t & 63) == 0) wavepart[(size_t)blockIdx.x * (PHIP_THREADS / 64) + (t >> 6)] = dacc;
+    if ((t & 63) == 0) wavepart[(size_t)bid * (PHIP_THREADS / 64) + (t >> 6)] = dacc;
   }
 }
 
@@ -2283,7 +2293,8 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
         nwg = (A->m + DMG_WG_ROWS - 1) / DMG_WG_ROWS;
 #define DMG_LAUNCH(ADDv)                                                                                                                                  \
   hipLaunchKernelGGL((spmv_dmaskg_kernel<DOT, ADDv>), dim3((unsigned)nwg), dim3(PHIP_THREADS), 0, st, A->m, A->n, reinterpret_cast<const DmWords *>(A->d_tmask), \
-                     reinterpret_cast<const phip_u32x16 *>(A->d_gdesc), A->dm_ndesc, A->dm_dmin, A->dm_dmax, d_x, d_yin, d_yout, d_v, part, nty)
+                     reinterpret_cast<const phip_u32x16 *>(A->d_gdesc), A->dm_ndesc, A->dm_dmin, A->dm_dmax, d_x, d_yin, d_yout, d_v, part, nty, xcd_map)
+        static const int xcd_map = getenv("PHIP_SPMV_XCD_MAP") ? atoi(getenv("PHIP_SPMV_XCD_MAP")) : 0;
         if (add) DMG_LAUNCH(true); else DMG_LAUNCH(false);
 #undef DMG_LAUNCH
       } else if (dm_rows_env != 2) {
