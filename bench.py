@@ -142,9 +142,10 @@ def layout_of(L, hA, m, n, nz):
         return "spmv_rowblock_kernel", "CSR row blocks (12 B/nz)" + (", x gathered in hot-column order (+20 B/column)" if hu_.value else ""), real, alg
     if dmu_.value:
         if m >= (4 << 20):  # the library's size rule (phip_set_dmask_kernel)
-            nwaves = 4 * ((m + 1023) // 1024)
-            return ("spmv_dmaskg_kernel", "diagonal masks: %d (diagonal, value) pairs in 64-byte group descriptors; per wave of 256 rows and pair four 64-bit lane masks (33 x 32 B per wave), four rows a lane" % dmn_.value,
-                    33 * 32 * nwaves + 8 * n + 8 * m, alg)
+            ns_, nw_ = C.c_int64(), C.c_int64()
+            L.phip_mat_mask_sets_info(hA, C.byref(ns_), C.byref(nw_))
+            return ("spmv_dmaskg_kernel", "diagonal masks: %d (diagonal, value) pairs in 64-byte group descriptors; per wave of 256 rows and pair four 64-bit lane masks, equal sets stored once (%d sets of 33 x 32 B for %d waves + 4 B per wave), four rows a lane" % (dmn_.value, ns_.value, nw_.value),
+                    33 * 32 * ns_.value + 4 * nw_.value + 8 * n + 8 * m, alg)
         return ("spmv_dmask4_kernel", "diagonal masks: %d (diagonal, value) pairs, a 32-bit set of them per row (4 B/row), four rows a lane" % dmn_.value,
                 4 * 512 * nsl + 8 * n + 8 * m, alg)
     if vdu_.value:

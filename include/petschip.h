@@ -168,6 +168,9 @@ int phip_set_setup_threads(int nthreads);
  * 4 / 5: that kernel for every size; 6: spmv_dmasks_kernel, the group-descriptor kernel with the windows of x staged in LDS (a third of
  * the L1 traffic for a 27-point stencil, but measured slower: never chosen by itself).  PHIP_DMASK_KERNEL sets the initial value. */
 int phip_set_dmask_kernel(int kind);
+/* the transposed masks of spmv_dmaskg_kernel: waves (of 256 rows) and distinct sets of mask words among them (equal sets are stored
+ * once, 1056 bytes each, plus a 4-byte set number per wave); 0 / 0 without the diagonal-mask layout */
+int phip_mat_mask_sets_info(phip_mat A, int64_t *nsets, int64_t *nwaves);
 int phip_mat_set_diag_mask(phip_mat A, int on);
 int phip_mat_diag_mask_info(phip_mat A, int *built, int *in_use, int32_t *npairs);
 /* tuning: SELL-dict kernel gathers x from LDS-staged contiguous segments (one per cluster of nearby diagonals) instead of through

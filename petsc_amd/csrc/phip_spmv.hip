@@ -38,6 +38,7 @@
 #include <atomic>
 #include <chrono>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #define SPMV_CAP 2046          /* nonzeros per row block; +2 alignment slack = 2048 LDS doubles = 16 KiB */
@@ -134,7 +135,9 @@ struct phip_mat_s {
   int       dm_built, dm_on;
   int32_t   dm_npairs;
   uint32_t *d_rmask;  /* [S * 512] bit q of rmask[r]: row r holds pair q */
-  unsigned long long *d_tmask; /* the same bits transposed (spmv_dmaskg_kernel): [wave of 256 rows][pair q, 33 entries][i] bit l: row 256 wave + 4 l + i holds pair q */
+  unsigned long long *d_tmask; /* the same bits transposed (spmv_dmaskg_kernel): [set][pair q, 33 entries][i] bit l: row 256 wave + 4 l + i holds pair q, for the waves of that set */
+  int32_t  *d_widx;   /* [wave of 256 rows] the wave's set in d_tmask (equal sets are stored once) */
+  int64_t   dm_nsets;
   int       dm_dmin, dm_dmax; /* smallest / largest diagonal of the pair table */
   void     *d_gdesc;  /* [dm_ndesc + 3] DmGroup: the groups of spmv_dmaskg_kernel (at most one pair per place of the window) */
   int       dm_ndesc;
@@ -794,7 +797,7 @@ __device__ __forceinline__ void dmg_step(double (&s)[4], const double (&w)[DM4_W
    dmin / dmax: smallest and largest diagonal of the table: a wave all of whose windows stay inside x (all but the first and last few)
    takes the loop without range tests. */
 template <bool DOT, bool ADD>
-__global__ __launch_bounds__(PHIP_THREADS) void spmv_dmaskg_kernel(int32_t m, int32_t n, const DmWords *__restrict__ tmask, const phip_u32x16 *__restrict__ gdesc,
+__global__ __launch_bounds__(PHIP_THREADS) void spmv_dmaskg_kernel(int32_t m, int32_t n, const DmWords *__restrict__ tmask, const int32_t *__restrict__ widx, const phip_u32x16 *__restrict__ gdesc,
                                                                    int ngroups, int dmin, int dmax, const double *__restrict__ x, const double *__restrict__ yin,
                                                                    double *__restrict__ yout, const double *__restrict__ dotv, double *__restrict__ wavepart, int nty, int xcdmap)
 {
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmaskg_kernel(int32_t m, in
   }
 #pragma unroll
   for (int i = 0; i < DM4_ROWS; i++) s[i] = y0[i];
-  const DmWords *tmw = tmask + (size_t)wave * DMG_WORDS;
+  const DmWords *tmw = tmask + (size_t)__builtin_amdgcn_readfirstlane(widx[wave]) * DMG_WORDS; /* the wave's set of mask words */
   auto run = [&](auto fastc) {
     constexpr bool FAST = decltype(fastc)::value;
     DmGroup nxt = __builtin_bit_cast(DmGroup, gdesc[0]);
@@ -902,7 +905,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmaskg_kernel(int32_t m, in
    lanes l, l + 8, l + 16, l + 24 of a half-wave meet in the same banks (measured: 132 us against 90 us for the unstaged kernel) */
 #define DMS_PAD(e) ((e) + ((e) >> 5))
 template <bool DOT, bool ADD>
-__global__ __launch_bounds__(PHIP_THREADS) void spmv_dmasks_kernel(int32_t m, int32_t n, const DmWords *__restrict__ tmask, const phip_u32x16 *__restrict__ gdesc,
+__global__ __launch_bounds__(PHIP_THREADS) void spmv_dmasks_kernel(int32_t m, int32_t n, const DmWords *__restrict__ tmask, const int32_t *__restrict__ widx, const phip_u32x16 *__restrict__ gdesc,
                                                                    const int4 *__restrict__ segs, int nseg, int smin, int smax, const double *__restrict__ x,
                                                                    const double *__restrict__ yin, double *__restrict__ yout, const double *__restrict__ dotv,
                                                                    double *__restrict__ wavepart, int nty)
@@ -926,7 +929,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmasks_kernel(int32_t m, in
   }
 #pragma unroll
   for (int i = 0; i < DM4_ROWS; i++) s[i] = y0[i];
-  const DmWords *tmw = tmask + (size_t)wave * DMG_WORDS;
+  const DmWords *tmw = tmask + (size_t)__builtin_amdgcn_readfirstlane(widx[wave]) * DMG_WORDS; /* the wave's set of mask words */
   auto run = [&](auto fastc) {
     constexpr bool FAST = decltype(fastc)::value;
     phip_v2d_u st[DMS_STAGE];
@@ -1651,7 +1654,8 @@ static void free_pairs(phip_mat A)
 
 static void free_dmask(phip_mat A)
 {
-  if (A->ctx->device >= 0) { hipFree(A->d_rmask); hipFree(A->d_dmoffs); hipFree(A->d_dmvals); hipFree(A->d_dotpart); hipFree(A->d_dmgrp); hipFree(A->d_tmask); hipFree(A->d_gdesc); hipFree(A->d_segs); }
+  if (A->ctx->device >= 0) { hipFree(A->d_rmask); hipFree(A->d_dmoffs); hipFree(A->d_dmvals); hipFree(A->d_dotpart); hipFree(A->d_dmgrp); hipFree(A->d_tmask); hipFree(A->d_widx); hipFree(A->d_gdesc); hipFree(A->d_segs); }
+  A->d_widx = NULL; A->dm_nsets = 0;
   A->d_tmask = NULL; A->d_gdesc = NULL; A->dm_ndesc = 0; A->d_segs = NULL; A->dm_nseg = 0;
   A->d_rmask = NULL; A->d_dmoffs = NULL; A->d_dmvals = NULL; A->d_dotpart = NULL; A->d_dmgrp = NULL; A->dm_ngroups = 0; A->dm_built = 0; A->dm_on = 0; A->dm_npairs = 0;
 }
@@ -1768,8 +1772,34 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
       for (uint32_t miss = part & ~rmask[(size_t)(first + k)]; miss; miss &= miss - 1) tw[__builtin_ctz(miss) * 4 + (k & 3)] &= ~(1ull << (k >> 2));
   }
   });
+  /* most waves of a stencil matrix hold the same words (every interior line of the grid looks alike): keep each distinct set once and
+     give every wave the number of its set -- 27-point 256^3: 65 536 waves, a few dozen sets, 70 MB of masks become 0.3 MB, which is
+     what the product has to fetch again from HBM when it runs behind kernels that swept the caches (inside KSPCG) */
+  const size_t          setw = (size_t)DMG_WORDS * 4;
+  std::vector<int32_t>  widx(std::max<size_t>(nwaves, 1), 0);
+  size_t                nsets = 0;
+  {
+    std::unordered_map<uint64_t, std::vector<int32_t>> seen;
+    for (size_t wv = 0; wv < nwaves; wv++) {
+      const unsigned long long *tw = tmask.data() + wv * setw;
+      uint64_t                  hsh = 1469598103934665603ull;
+      for (size_t k = 0; k < setw; k++) { hsh ^= tw[k]; hsh *= 1099511628211ull; hsh ^= hsh >> 29; }
+      std::vector<int32_t> &cand = seen[hsh];
+      int32_t               found = -1;
+      for (int32_t c : cand) if (!memcmp(tmask.data() + (size_t)c * setw, tw, sizeof(unsigned long long) * setw)) { found = c; break; }
+      if (found < 0) { /* sets are compacted to the front of tmask in place: set number nsets <= wv */
+        found = (int32_t)nsets;
+        if (nsets != wv) memmove(tmask.data() + nsets * setw, tw, sizeof(unsigned long long) * setw);
+        cand.push_back(found);
+        nsets++;
+      }
+      widx[wv] = found;
+    }
+  }
+  A->dm_nsets = (int64_t)nsets;
   hipStream_t st = A->ctx->stream;
   if (!A->d_rmask) {
+    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_widx, sizeof(int32_t) * widx.size()));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_tmask, sizeof(unsigned long long) * tmask.size()));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_gdesc, sizeof(gd)));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_segs, sizeof(segs)));
@@ -1780,7 +1810,8 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dotpart, sizeof(double) * ((size_t)S * (PHIP_THREADS / 64) + 2)));
   }
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_rmask, rmask.data(), sizeof(uint32_t) * rmask.size(), hipMemcpyHostToDevice, st));
-  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_tmask, tmask.data(), sizeof(unsigned long long) * tmask.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_tmask, tmask.data(), sizeof(unsigned long long) * std::max<size_t>(nsets, 1) * setw, hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_widx, widx.data(), sizeof(int32_t) * widx.size(), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_gdesc, gd, sizeof(gd), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_segs, segs, sizeof(segs), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmoffs, offs, sizeof(offs), hipMemcpyHostToDevice, st));
@@ -2284,7 +2315,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
         nwg = (A->m + DMG_WG_ROWS - 1) / DMG_WG_ROWS;
         const size_t lds = sizeof(double) * (size_t)(DMS_PAD(A->dm_seg_maxlen) + 2);
 #define DMS_LAUNCH(ADDv)                                                                                                                                  \
-  hipLaunchKernelGGL((spmv_dmasks_kernel<DOT, ADDv>), dim3((unsigned)nwg), dim3(PHIP_THREADS), lds, st, A->m, A->n, reinterpret_cast<const DmWords *>(A->d_tmask), \
+  hipLaunchKernelGGL((spmv_dmasks_kernel<DOT, ADDv>), dim3((unsigned)nwg), dim3(PHIP_THREADS), lds, st, A->m, A->n, reinterpret_cast<const DmWords *>(A->d_tmask), A->d_widx, \
                      reinterpret_cast<const phip_u32x16 *>(A->d_gdesc), reinterpret_cast<const int4 *>(A->d_segs), A->dm_nseg, A->dm_smin, A->dm_smax, d_x, d_yin, \
                      d_yout, d_v, part, nty)
         if (add) DMS_LAUNCH(true); else DMS_LAUNCH(false);
@@ -2292,7 +2323,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
       } else if (dm_rows_env != 2 && use_g) {
         nwg = (A->m + DMG_WG_ROWS - 1) / DMG_WG_ROWS;
 #define DMG_LAUNCH(ADDv)                                                                                                                                  \
-  hipLaunchKernelGGL((spmv_dmaskg_kernel<DOT, ADDv>), dim3((unsigned)nwg), dim3(PHIP_THREADS), 0, st, A->m, A->n, reinterpret_cast<const DmWords *>(A->d_tmask), \
+  hipLaunchKernelGGL((spmv_dmaskg_kernel<DOT, ADDv>), dim3((unsigned)nwg), dim3(PHIP_THREADS), 0, st, A->m, A->n, reinterpret_cast<const DmWords *>(A->d_tmask), A->d_widx, \
                      reinterpret_cast<const phip_u32x16 *>(A->d_gdesc), A->dm_ndesc, A->dm_dmin, A->dm_dmax, d_x, d_yin, d_yout, d_v, part, nty, xcd_map)
         static const int xcd_map = getenv("PHIP_SPMV_XCD_MAP") ? atoi(getenv("PHIP_SPMV_XCD_MAP")) : 0;
         if (add) DMG_LAUNCH(true); else DMG_LAUNCH(false);
@@ -2613,6 +2644,14 @@ extern "C" int phip_mat_hot_columns_info(phip_mat A, int *built, int *in_use, do
 
 /* hot columns resident in LDS (setup_lds): on = 0 runs the row-block kernel, 1 the wave kernel built at creation (error if none was
    built).  info: built / in use / K / share of the nonzeros whose column is one of the K. */
+extern "C" int phip_mat_mask_sets_info(phip_mat A, int64_t *nsets, int64_t *nwaves)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_mask_sets_info: null matrix");
+  if (nsets) *nsets = A->dm_built ? A->dm_nsets : 0;
+  if (nwaves) *nwaves = A->dm_built ? (((int64_t)A->m + DMG_WG_ROWS - 1) / DMG_WG_ROWS) * (PHIP_THREADS / 64) : 0;
+  return 0;
+}
+
 extern "C" int phip_set_setup_threads(int nthreads)
 {
   PHIP_REQUIRE(nthreads >= 0 && nthreads <= 64, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_setup_threads: %d (0: default, at most 64)", nthreads);

@@ -94,6 +94,9 @@ def test_default_group_descriptor_mask_kernel(ctx):
     db, du, dn = C.c_int(), C.c_int(), C.c_int32()
     ctx.check(L.phip_mat_diag_mask_info(A, C.byref(db), C.byref(du), C.byref(dn)))
     assert (db.value, du.value) == (1, 1) and dn.value <= 32
+    ns, nw = C.c_int64(), C.c_int64()
+    ctx.check(L.phip_mat_mask_sets_info(A, C.byref(ns), C.byref(nw)))
+    assert nw.value == 4 * ((m + 1023) // 1024) and 1 <= ns.value <= nw.value // 10   # the lines of the grid share few sets of mask words
     x = np.random.default_rng(8).uniform(-1.0, 1.0, m)
     y0 = np.random.default_rng(9).uniform(-1.0, 1.0, m)
     dx, dy, dy0 = ctx.to_device(x), ctx.to_device(np.zeros(m)), ctx.to_device(y0)
