@@ -141,7 +141,7 @@ def layout_of(L, hA, m, n, nz):
         real = 12 * nz + 4 * (m + 1) + 8 * n + 8 * m + 5 * nb.value + (20 * n if hu_.value else 0)
         return "spmv_rowblock_kernel", "CSR row blocks (12 B/nz)" + (", x gathered in hot-column order (+20 B/column)" if hu_.value else ""), real, alg
     if dmu_.value:
-        if m >= (4 << 20):  # the library's size rule (phip_set_dmask_kernel)
+        if m >= (4 << 20) or dmn_.value >= 12:  # the library's rule (phip_set_dmask_kernel)
             ns_, nw_ = C.c_int64(), C.c_int64()
             L.phip_mat_mask_sets_info(hA, C.byref(ns_), C.byref(nw_))
             return ("spmv_dmaskg_kernel", "diagonal masks: %d (diagonal, value) pairs in 64-byte group descriptors; per wave of 256 rows and pair four 64-bit lane masks, equal sets stored once (%d sets of 33 x 32 B for %d waves + 4 B per wave), four rows a lane" % (dmn_.value, ns_.value, nw_.value),

@@ -164,7 +164,8 @@ int phip_set_default_diag_mask(int mode);
  * depend on the number of threads.  27-point 256^3 (449 M nonzeros): phip_mat_create 3.8 s on one thread, 1.1 s on 16. */
 int phip_set_setup_threads(int nthreads);
 /* which of the two diagonal-mask kernels runs (same bits): 0 (default) by size -- spmv_dmaskg_kernel (group descriptors and transposed
- * masks read by the scalar unit, the masks as execution masks) from 4 Mi rows on, spmv_dmask4_kernel (a bit set per row) below --
+ * masks read by the scalar unit, the masks as execution masks) from 4 Mi rows on or with 12 pairs and more, spmv_dmask4_kernel (a bit
+ * set per row) otherwise --
  * 4 / 5: that kernel for every size; 6: spmv_dmasks_kernel, the group-descriptor kernel with the windows of x staged in LDS (a third of
  * the L1 traffic for a 27-point stencil, but measured slower: never chosen by itself).  PHIP_DMASK_KERNEL sets the initial value. */
 int phip_set_dmask_kernel(int kind);

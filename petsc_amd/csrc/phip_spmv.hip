@@ -2303,11 +2303,12 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
       static const int dm_rows_env = getenv("PHIP_DMASK_ROWS") ? atoi(getenv("PHIP_DMASK_ROWS")) : 4;
       static const int dm_ug_env = getenv("PHIP_DMASK_GROUPS") ? atoi(getenv("PHIP_DMASK_GROUPS")) : 0;
       int              nwg;
-      /* spmv_dmaskg_kernel from 4 Mi rows on, spmv_dmask4_kernel below (27-point 256^3: 116 -> 91 us with the former; 7-point 128^3
-         inside KSPCG 18.2 k it/s with the latter against 17.6 k: its launches are 10 us long and start from cold scalar caches);
+      /* spmv_dmaskg_kernel from 4 Mi rows on and for matrices with 12 pairs and more, spmv_dmask4_kernel otherwise (27-point 256^3:
+         116 -> 87 us with the former, 27-point 128^3 21.2 -> 15.9 us and KSPCG 13.95 k -> 14.96 k it/s; 7-point 128^3 inside KSPCG 1 %
+         better with the latter: its launches are 10 us long and start from cold scalar caches);
          PHIP_DMASK_KERNEL / phip_set_dmask_kernel: 4 or 5 (the group-descriptor kernel) for all sizes */
       if (g_dm_kernel < 0) g_dm_kernel = getenv("PHIP_DMASK_KERNEL") ? atoi(getenv("PHIP_DMASK_KERNEL")) : 0;
-      const bool use_g = g_dm_kernel == 5 || (g_dm_kernel != 4 && A->m >= DMG_MIN_ROWS);
+      const bool use_g = g_dm_kernel == 5 || (g_dm_kernel != 4 && g_dm_kernel != 6 && (A->m >= DMG_MIN_ROWS || A->dm_npairs >= 12));
       /* 6: the same with the windows staged in LDS (spmv_dmasks_kernel); requests dm_l1_ratio times fewer entries from the L1 (27-point:
          3 x) but measured slower, so never by default */
       const bool use_s = A->dm_nseg > 0 && g_dm_kernel == 6;
@@ -2324,7 +2325,11 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
         nwg = (A->m + DMG_WG_ROWS - 1) / DMG_WG_ROWS;
 #define DMG_LAUNCH(ADDv)                                                                                                                                  \
   hipLaunchKernelGGL((spmv_dmaskg_kernel<DOT, ADDv>), dim3((unsigned)nwg), dim3(PHIP_THREADS), 0, st, A->m, A->n, reinterpret_cast<const DmWords *>(A->d_tmask), A->d_widx, \
-                     reinterpret_cast<const phip_u32x16 *>(A->d_gdesc), A->dm_ndesc, A->dm_dmin, A->dm_dmax, d_x, d_yin, d_yout, d_v, part, nty, xcd_map)
+                     reinterpret_cast<const phip_u32x16 *>(A->d_gdesc), A->dm_ndesc, A->dm_dmin, A->dm_dmax, d_x, d_yin, d_yout, d_v, part, nty_g, xcd_map)
+        /* this kernel stores its result with plain stores at every size: the next kernel of a Krylov iteration reads it back (KSPCG: the
+           batch behind the product), and with the kernel's small footprint the non-temporal stores no longer protect anything -- KSPCG
+           27-point 256^3 2889 -> 2917 it/s, 7-point 256^3 3053 -> 3173 it/s (product 64.9 -> 54.9 us); PHIP_SPMV_NT_Y=1 forces them */
+        const int nty_g = nty_env >= 0 ? nty_env : 0;
         static const int xcd_map = getenv("PHIP_SPMV_XCD_MAP") ? atoi(getenv("PHIP_SPMV_XCD_MAP")) : 0;
         if (add) DMG_LAUNCH(true); else DMG_LAUNCH(false);
 #undef DMG_LAUNCH
