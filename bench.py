@@ -13,7 +13,8 @@ scaling: the same global matrix cut into MPIAIJ row blocks (z-slabs), ghost exch
 GPU, so N = 1 runs it too and value(N) / value(1) is the strong-scaling speed-up the >= 6x target is quoted on.
 
 value    = whole-job ALGORITHMIC bytes of the K iterations / wall time (GB/s): per rank and iteration SpMV 12 nz + 20 m + 4 (+ the
-           off-diagonal block's MultAdd 12 nzB + 28 mB on N > 1) + 136 m of vector kernels.  KSPCG iterations/s ride along.
+           off-diagonal block's MultAdd 12 nzB + 28 mB on N > 1) + 136 m of vector kernels (the reference's
+           passes; the library's two fused launches move 80 m).  KSPCG iterations/s ride along.
 roofline = the kernel with the largest share of the timed iteration, priced on the bytes it REALLY moves in its device layout (never
            more than the algorithmic CSR bytes) over its average launch time: frac <= 1 by construction.  The algorithmic figure
            (12 nz + 20 m + 4 over the same time) is reported beside it as effective_GBps.  Every other kernel of the iteration and
@@ -183,8 +184,12 @@ def roofline_obj(workload, kernel, layout, real_bytes, alg_bytes, avg_us, pcts, 
     return o
 
 
-def vec_kernels(L, ctx, tm, m, workload=""):
-    """the two vector launches of a KSPCG iteration (cg.c:222-229 batch with its three fused sums; VecAYPX cg.c:202), back to back"""
+def vec_kernels(L, ctx, tm, m, workload="", incg_batch=None, incg_xp=None):
+    """the two vector launches of a KSPCG iteration: cg_update_kernel = VecAXPY(R,-a,W) + VecPointwiseMult(Z,D,R) with its three fused sums
+    (cg.c:223-229), and xp_update_kernel = VecAXPY(X,a,P) (cg.c:222, deferred) + VecAYPX(P,b,Z) (cg.c:202).  Back to back: the pair, and
+    the second kernel alone (the first cannot be launched alone through the API: it exists only as what is left of KSPCG's batch);
+    incg_*: their per-launch durations inside the timed solve (phip_profile_durations kinds 2 and 3), which is what avg_launch_us
+    reports when present."""
     from petsc_amd.capi import Context, Ticket
     dev = Context.__new__(Context)
     dev.lib, dev.h = L, ctx
@@ -193,20 +198,33 @@ def vec_kernels(L, ctx, tm, m, workload=""):
     vz = vw  # KSPCG keeps W and Z in one work vector (cg.c:106)
     tk = Ticket()
 
-    def cg_batch():
+    def pair():
         L.phip_vec_axpy(ctx, m, vx, 1e-3, vp)
         L.phip_vec_axpy(ctx, m, vr, -1e-3, vw)
         L.phip_vec_pointwise_mult_reduce(ctx, m, vz, vd, vr, 0, C.byref(tk))
-
-    def aypx():
         L.phip_vec_aypx(ctx, m, vp, 0.5, vz)
-        L.phip_stream(ctx)  # launches what is pending: one AYPX per launch, as inside the iteration
+        L.phip_stream(ctx)  # launches what is pending, as the next MatMult does
 
+    def xp():
+        L.phip_vec_axpy(ctx, m, vx, 1e-3, vp)
+        L.phip_vec_aypx(ctx, m, vp, 0.5, vz)
+        L.phip_stream(ctx)
+
+    pair_us, _ = tm.kernel(pair, REPS, 10)
+    xp_us, xp_pcts = tm.kernel(xp, REPS, 10)
     out = {}
-    for name, kern, fn, nbytes, what in (("cg_batch", "cg_update_kernel", cg_batch, 64 * m, "VecAXPY(X,a,P) + VecAXPY(R,-a,W) + VecPointwiseMult(Z,D,R) with 3 fused sums, one launch: 5 vectors read, 3 written"),
-                                         ("aypx", "ew_kernel<AYPX>", aypx, 24 * m, "VecAYPX(P,b,Z): 2 vectors read, 1 written")):
-        avg, pcts = tm.kernel(fn, REPS, 10)
-        out[name] = roofline_obj(workload, kern, "contiguous double[m]", nbytes, nbytes, avg, pcts, resident_bytes=nbytes, extra={"what": what})
+    for name, kern, nbytes, what, b2b, pcts, incg in (
+            ("cg_batch", "cg_update_kernel", 40 * m, "VecAXPY(R,-a,W) + VecPointwiseMult(Z,D,R) with 3 fused sums, one launch: 3 vectors read, 2 written", pair_us - xp_us, None, incg_batch),
+            ("xp_update", "xp_update_kernel", 40 * m, "VecAXPY(X,a,P) (deferred) + VecAYPX(P,b,Z), one launch: 3 vectors read, 2 written", xp_us, xp_pcts, incg_xp)):
+        if incg:
+            avg = float(np.mean(incg)) * 1e3
+            p3 = [round(pct(incg, q) * 1e3, 2) for q in (10, 50, 90)]
+            src = "inside the timed KSPCG solve (hipEvent pair per launch, %d launches)" % len(incg)
+        else:
+            avg, p3, src = b2b, pcts, "back to back"
+        out[name] = roofline_obj(workload, kern, "contiguous double[m]", nbytes, nbytes, avg, p3, resident_bytes=nbytes,
+                                 extra={"what": what, "timed": src, "back_to_back_us": round(b2b, 2),
+                                        "back_to_back_is": "pair of both vector kernels minus the second alone" if name == "cg_batch" else "200 launches between two events"})
     for v in vecs:
         dev.free(v)
     return out
@@ -350,19 +368,27 @@ def main():
 
     run(max(a.warmup, 1))
     barrier()
-    L.phip_profile_enable(comm.ctx, 1)
     t1 = time.perf_counter()
     res = run(a.steps)
     barrier()
     dt = time.perf_counter() - t1
+    # the same solve once more, untimed, with a hipEvent pair around every launch: per-launch durations of the three kernels inside KSPCG
+    x.set(1.0)
+    L.phip_profile_enable(comm.ctx, 1)
+    run(a.steps)
+    barrier()
     cap = a.steps + 8
     dur = (C.c_float * cap)()
     cnt = C.c_int32()
     L.phip_profile_durations(comm.ctx, 0, cap, dur, C.byref(cnt))
-    L.phip_profile_enable(comm.ctx, 0)
     assert res["its"] == a.steps, "CG stopped after %d of %d iterations (reason %d)" % (res["its"], a.steps, res["reason"])
     incg = [dur[i] for i in range(min(cnt.value, cap))]
     spmv_ms = float(np.mean(incg)) if incg else 0.0
+    incg_vec = {}
+    for kind_ in (2, 3):  # the reducing batch / the pending elementwise operations launched by the next MatMult
+        L.phip_profile_durations(comm.ctx, kind_, cap, dur, C.byref(cnt))
+        incg_vec[kind_] = [dur[i] for i in range(min(cnt.value, cap))][2:]  # the first launches belong to KSPSolve's set-up (other shapes)
+    L.phip_profile_enable(comm.ctx, 0)
 
     # the diagonal-block SpMV kernel alone (kernel-level handle of the matrix the solve used), then the whole MatMult (ghost exchange
     # + diagonal block + off-diagonal block on N > 1)
@@ -384,7 +410,7 @@ def main():
         lv.free(dl)
     y2.destroy()
     x.set_array(xsave)
-    vk = vec_kernels(L, comm.ctx, tm, m, a.workload if world == 1 else "")
+    vk = vec_kernels(L, comm.ctx, tm, m, a.workload if world == 1 else "", incg_vec.get(2), incg_vec.get(3))
 
     tot = np.array([float(iter_bytes), float(spmv_bytes + spmv_add_bytes), float(dt), float(spmv_ms), float(b2b_us), float(mm_us), float(m), float(nz_local)])
     if dist is not None:
@@ -413,7 +439,7 @@ def main():
         spmv_roof["launch_us_inside_cg_p10_p50_p90"] = [round(pct(incg, q) * 1e3, 2) for q in (10, 50, 90)] if incg else None
         spmv_roof["inside_cg_note"] = "inside KSPCG the product also leaves sum_i x_i y_i (the VecTDot(P,W) of cg.c:207) and is bracketed by an event pair per launch"
         # which kernel owns the largest share of the timed iteration?
-        shares = {"spmv": spmv_ms * 1e3 if incg else b2b_us, "cg_batch": vk["cg_batch"]["avg_launch_us"], "aypx": vk["aypx"]["avg_launch_us"]}
+        shares = {"spmv": spmv_ms * 1e3 if incg else b2b_us, "cg_batch": vk["cg_batch"]["avg_launch_us"], "xp_update": vk["xp_update"]["avg_launch_us"]}
         dom = max(shares, key=shares.get)
         roof = dict(spmv_roof if dom == "spmv" else vk[dom])
         roof["share_of_iteration_us"] = {k: round(v, 2) for k, v in shares.items()}
@@ -437,7 +463,7 @@ def main():
                      "algorithmic_bytes_all_ranks": int(job_spmv_bytes), "launches_timed": REPS,
                      "note": "matmult = the whole MatMult (N > 1: pack + ghost exchange overlapped with the diagonal block, then the off-diagonal block); exchange cost not hidden = matmult - diag - offdiag"},
             "roofline": roof,
-            "kernels": {"spmv": spmv_roof, "cg_batch": vk["cg_batch"], "aypx": vk["aypx"]},
+            "kernels": {"spmv": spmv_roof, "cg_batch": vk["cg_batch"], "xp_update": vk["xp_update"]},
             "final_rnorm": res["rnorm"], "setup_s": round(setup_s, 2),
         }
         if world > 1:

@@ -80,7 +80,9 @@ int         phip_event_elapsed_ms(phip_ctx ctx, void *start, void *stop, float *
 int         phip_event_destroy(phip_ctx ctx, void *event);
 /* Per-launch device timing of the SpMV kernel (the role of the MAT_Mult event of -log_view, src/mat/interface/matrix.c:2224-2226):
  * while enabled, every phip_mat_mult (kind 0) / phip_mat_multadd (kind 1) launch is bracketed by a hipEvent pair on the compute
- * stream.  phip_profile_read synchronises and returns the number of launches recorded since enable and their summed / extreme
+ * stream; so are the launch of a batch of elementwise operations that leaves with a reducing pointwise product (kind 2: KSPCG's
+ * VecAXPY(R,-a,W) + PCApply with its sums) and every other launch of pending elementwise operations (kind 3: KSPCG's VecAXPY(X,a,P) +
+ * VecAYPX(P,b,Z)).  phip_profile_read synchronises and returns the number of launches recorded since enable and their summed / extreme
  * durations in ms.  Enabling (or re-enabling) clears the records. */
 int         phip_profile_enable(phip_ctx ctx, int on);
 int         phip_profile_read(phip_ctx ctx, int kind, int32_t *count, double *sum_ms, double *min_ms, double *max_ms);
@@ -218,6 +220,11 @@ int phip_mat_lds_hot_info(phip_mat A, int *built, int *in_use, int32_t *K, doubl
 /* tuning, process-wide: non-temporal loads (and stores of X and R in the KSPCG batch) in the elementwise kernels: -1 (default) for vectors
  * of 48 MiB and more, 0 never, 1 always.  Same bits either way.  PHIP_EW_NT in the environment sets the initial value. */
 int phip_set_ew_nontemporal(int mode);
+/* KSPCG's VecAXPY(X,a,P) (cg.c:222) is independent of the rest of its batch (VecAXPY(R,-a,W); PCApply with its sums) and P is read again
+ * by the VecAYPX(P,b,Z) of the next iteration (cg.c:202): by default it stays pending when the batch leaves and is launched together with
+ * that operation in one kernel that reads P once (xp_update_kernel).  Same arithmetic, same bits; every other entry point launches what
+ * is pending first, so nobody can see the old X.  0 switches it off (PHIP_CG_DEFER_X=0 sets the initial value). */
+int phip_set_cg_defer_x(int on);
 int phip_vec_dot(phip_ctx ctx, int32_t n, const double *d_x, const double *d_y, double *h_z);        /* VecDot_Seq/VecTDot_Seq bvec1.c:12-51 */
 int phip_vec_norm(phip_ctx ctx, int32_t n, const double *d_x, int type, double *h_z);                /* VecNorm_Seq bvec2.c:233-271 (h_z[2] for 1_AND_2) */
 int phip_vec_mdot(phip_ctx ctx, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *h_z); /* VecMDot_Seq dvec2.c:98-294 */

@@ -69,6 +69,7 @@ SIGNATURES = [
     ("phip_set_default_lds_hot", C.c_int, [C.c_int]),
     ("phip_set_dmask_kernel", C.c_int, [C.c_int]),
     ("phip_set_setup_threads", C.c_int, [C.c_int]),
+    ("phip_set_cg_defer_x", C.c_int, [C.c_int]),
     ("phip_mat_mask_sets_info", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("phip_halo_ipc_count", C.c_int, [C.POINTER(C.c_ulonglong)]),
     ("phip_mat_set_lds_hot", C.c_int, [_vp, C.c_int]),

@@ -6,8 +6,8 @@
 #include <vector>
 
 struct phip_prof_s {
-  std::vector<hipEvent_t> ev[2][2]; /* [kind][start|stop] */
-  size_t                  used[2];
+  std::vector<hipEvent_t> ev[4][2]; /* [kind][start|stop]; kinds: include/petschip.h phip_profile_read */
+  size_t                  used[4];
 };
 
 static thread_local char g_err[512] = "";
@@ -289,7 +289,7 @@ extern "C" int phip_event_destroy(phip_ctx c, void *event)
 
 int phip_prof_open(phip_ctx c, int kind, hipEvent_t *start, hipEvent_t *stop)
 {
-  if (!c->prof) { c->prof = new phip_prof_s(); c->prof->used[0] = c->prof->used[1] = 0; }
+  if (!c->prof) { c->prof = new phip_prof_s(); for (int k = 0; k < 4; k++) c->prof->used[k] = 0; }
   phip_prof_s *p = c->prof;
   if (p->used[kind] == p->ev[kind][0].size()) {
     hipEvent_t a, b;
@@ -308,14 +308,14 @@ extern "C" int phip_profile_enable(phip_ctx c, int on)
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_profile_enable: null context");
   PHIP_NEED_DEVICE(c, "phip_profile_enable");
   c->prof_on = on ? 1 : 0;
-  if (c->prof) c->prof->used[0] = c->prof->used[1] = 0;
+  if (c->prof) for (int k = 0; k < 4; k++) c->prof->used[k] = 0;
   return 0;
 }
 
 extern "C" int phip_profile_read(phip_ctx c, int kind, int32_t *count, double *sum_ms, double *min_ms, double *max_ms)
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_profile_read: null context");
-  PHIP_REQUIRE(kind == 0 || kind == 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_profile_read: kind %d", kind);
+  PHIP_REQUIRE(kind >= 0 && kind <= 3, PHIP_ERR_ARG_OUTOFRANGE, "phip_profile_read: kind %d", kind);
   PHIP_NEED_DEVICE(c, "phip_profile_read");
   PHIP_FLUSH(c);
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
@@ -343,7 +343,7 @@ extern "C" int phip_profile_read(phip_ctx c, int kind, int32_t *count, double *s
 extern "C" int phip_profile_durations(phip_ctx c, int kind, int32_t cap, float *h_ms, int32_t *count)
 {
   PHIP_REQUIRE(c && count && (h_ms || cap <= 0), PHIP_ERR_ARG_NULL, "phip_profile_durations: null argument");
-  PHIP_REQUIRE(kind == 0 || kind == 1, PHIP_ERR_ARG_OUTOFRANGE, "phip_profile_durations: kind %d", kind);
+  PHIP_REQUIRE(kind >= 0 && kind <= 3, PHIP_ERR_ARG_OUTOFRANGE, "phip_profile_durations: kind %d", kind);
   PHIP_NEED_DEVICE(c, "phip_profile_durations");
   PHIP_FLUSH(c);
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));

@@ -1005,6 +1005,48 @@ def test_cg_update_batch(orc, n):
         assert np.abs(g[3] - exact).max() <= 1e-12 * scale and np.abs(g[3] - r[3]).max() <= 1e-12 * scale
 
 
+@pytest.mark.parametrize("n", [1, 2, 1001, 300000, 8388609])
+def test_cg_deferred_x_update(ctx, n):
+    """KSPCG's VecAXPY(X,a,P) stays pending when the rest of its batch leaves with the reducing product, and is launched with the
+    VecAYPX(P,b,Z) that follows in one kernel reading P once (xp_update_kernel): two iterations' worth of calls give the same bits in
+    X, P, R, Z and the same sums as with the deferral switched off; a read of X in between sees the updated X."""
+    import ctypes as C
+    from petsc_amd.capi import Ticket
+    L = ctx.lib
+    rng = np.random.default_rng(5)
+    x0, p0, r0, w0, d0 = (rng.standard_normal(n) for _ in range(5))
+    res = {}
+    for on in (1, 0):
+        ctx.check(L.phip_set_cg_defer_x(on))
+        try:
+            dx, dp, dr, dw, dd = (ctx.to_device(v) for v in (x0, p0, r0, w0, d0))
+            sums, peek = [], None
+            for it in range(2):
+                ctx.check(L.phip_vec_axpy(ctx.h, n, dx, 0.375 + it, dp))          # X += a P
+                ctx.check(L.phip_vec_axpy(ctx.h, n, dr, -0.375 - it, dw))         # R -= a W
+                t = Ticket()
+                ctx.check(L.phip_vec_pointwise_mult_reduce(ctx.h, n, dw, dd, dr, 1, C.byref(t)))   # Z = D .* R, Z is W (cg.c:106)
+                red = np.zeros(3)
+                ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t), red.ctypes.data_as(C.POINTER(C.c_double))))
+                sums.append(red)
+                if it == 0:
+                    ctx.check(L.phip_vec_aypx(ctx.h, n, dp, 0.625, dw))          # P = Z + b P: leaves together with the pending X update
+                    ctx.check(L.phip_vec_scale(ctx.h, n, dw, 2.0))               # another operation behind them
+                else:
+                    peek = ctx.to_host(dx, n)                                    # the caller looks at X while its update is pending
+            res[on] = [ctx.to_host(v, n) for v in (dx, dp, dr, dw)] + [peek] + sums
+            for v in (dx, dp, dr, dw, dd):
+                ctx.free(v)
+        finally:
+            ctx.check(L.phip_set_cg_defer_x(1))
+    for a, b in zip(res[1], res[0]):
+        np.testing.assert_array_equal(a, b)
+    x1 = x0 + 0.375 * p0
+    p1 = d0 * (r0 - 0.375 * w0) + 0.625 * p0
+    assert np.abs(res[1][0] - (x1 + 1.375 * p1)).max() <= 1e-14 * max(1.0, np.abs(x1).max() + 2 * np.abs(p1).max())
+    np.testing.assert_array_equal(res[1][4], res[1][0])
+
+
 @pytest.mark.parametrize("n", [1, 2, 7, 1000, 300001])
 def test_batched_elementwise_ops(orc, n):
     """Elementwise operations wait in the context and leave in one launch (up to 4, call order kept per entry).  Chains in which each
