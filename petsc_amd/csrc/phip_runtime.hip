@@ -90,7 +90,7 @@ extern "C" int phip_finalize(phip_ctx c)
   hipHostFree(c->h_ll); hipHostFree(c->h_err); hipFree(c->d_ring); hipHostFree(c->h_ring);
   hipFree(c->d_partials); hipFree(c->d_result); hipHostFree(c->h_result); hipFree(c->d_flag); hipHostFree(c->h_flag);
   if (c->prof) {
-    for (int k = 0; k < 2; k++) for (int w = 0; w < 2; w++) for (hipEvent_t e : c->prof->ev[k][w]) hipEventDestroy(e);
+    for (int k = 0; k < 4; k++) for (int w = 0; w < 2; w++) for (hipEvent_t e : c->prof->ev[k][w]) hipEventDestroy(e);
     delete c->prof;
   }
   hipStreamDestroy(c->stream); hipStreamDestroy(c->comm_stream);
