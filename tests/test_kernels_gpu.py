@@ -745,6 +745,49 @@ def test_norm_inf_nan(ctx):
     ctx.free(dx)
 
 
+def test_mask_kernels_repeated_diagonals(ctx, orc):
+    """Diagonals that carry several values each (a coefficient with period 3 along the rows): the pair table then holds several pairs on
+    one diagonal, which the group descriptors must place in groups of their own (a place of the window holds one pair).  All mask
+    kernels against the oracle, bit for bit, on a 2-D 9-point stencil with 5 diagonals x 3 values + boundary variants <= 32 pairs."""
+    import ctypes as C
+    from petsc_amd import generators as G
+    L = ctx.lib
+    nx, ny = 70, 53
+    m = nx * ny
+    rows, cols, vals = [], [], []
+    for j in range(ny):
+        for i in range(nx):
+            r = j * nx + i
+            for dj, di in ((-1, 0), (0, -1), (0, 0), (0, 1), (1, 0)):
+                ii, jj = i + di, j + dj
+                if 0 <= ii < nx and 0 <= jj < ny:
+                    rows.append(r); cols.append(jj * nx + ii)
+                    vals.append((4.0 if (di, dj) == (0, 0) else -1.0) * (1.0 + 0.25 * (r % 3)) + (0.125 if dj else 0.0))
+    import scipy.sparse as sp
+    A0 = sp.csr_matrix((vals, (rows, cols)), shape=(m, m))
+    A0.sort_indices()
+    ai, aj, aa = A0.indptr.astype(np.int32), A0.indices.astype(np.int32), A0.data.astype(np.float64)
+    A = ctx.mat_create(m, m, ai, aj, aa)
+    db, du, dn = C.c_int(), C.c_int(), C.c_int32()
+    ctx.check(L.phip_mat_diag_mask_info(A, C.byref(db), C.byref(du), C.byref(dn)))
+    assert (db.value, du.value) == (1, 1) and 12 <= dn.value <= 32, dn.value     # 5 diagonals x 3 values
+    x, y0 = G.random_vector(m), np.random.default_rng(3).standard_normal(m)
+    dx, dy, dy0 = ctx.to_device(x), ctx.to_device(np.zeros(m)), ctx.to_device(y0)
+    ref = orc.matmult(ai, aj, aa, x)
+    for kind in (4, 5, 6):
+        ctx.check(L.phip_set_dmask_kernel(kind))
+        try:
+            ctx.check(L.phip_mat_mult(A, dx, dy))
+            np.testing.assert_array_equal(ctx.to_host(dy, m), ref)
+            ctx.check(L.phip_mat_multadd(A, dx, dy0, dy))
+            np.testing.assert_array_equal(ctx.to_host(dy, m), orc.matmultadd(ai, aj, aa, x, y0))
+        finally:
+            ctx.check(L.phip_set_dmask_kernel(0))
+    for p_ in (dx, dy, dy0):
+        ctx.free(p_)
+    ctx.check(L.phip_mat_destroy(A))
+
+
 def test_reductions_under_foreign_load(ctx):
     """The single-launch reductions let their last workgroup wait for the partial results of the others (phip_reduce.h: workgroups are
     dispatched in index order and at most 1024 of them exist, so all are resident).  Here that is exercised while ANOTHER PROCESS keeps
