@@ -311,10 +311,62 @@ def main():
         # data path: RCCL (one GPU per rank).  PHIP_BENCH_BACKEND=shm stages the ghost exchange through host shared memory instead, so
         # that the ranks may share a GPU: a rehearsal of this script's distributed flow on a one-GPU box, not a measurement.
         backend = os.environ.get("PHIP_BENCH_BACKEND", "rccl")
-        ids = [(P.Comm.unique_id() if backend == "rccl" else os.urandom(128)) if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
         ndev = max(torch.cuda.device_count(), 1)
-        comm = P.Comm(device=local_rank % ndev, backend=backend, id128=ids[0], nranks=world, rank=rank)
+
+        def make_comm(be):
+            """the communicator of all ranks, or (None, reason) on every rank when it cannot be brought up on one of them"""
+            why = ""
+            try:
+                ids = [(P.Comm.unique_id() if be == "rccl" else os.urandom(128)) if rank == 0 else None]
+            except Exception as e:  # ncclGetUniqueId failed on rank 0: the others must not wait for it in ncclCommInitRank
+                ids, why = [b""], "unique id: %s" % e
+            dist.broadcast_object_list(ids, src=0)
+            if not ids[0]:
+                return None, why or "rank 0 could not make the RCCL unique id"
+            cm = None
+            try:
+                cm = P.Comm(device=local_rank % ndev, backend=be, id128=ids[0], nranks=world, rank=rank)
+                if be == "rccl":  # one ncclAllReduce, so that a broken RCCL shows here and not in the middle of the set-up
+                    lv = capi.Context.__new__(capi.Context)
+                    lv.lib, lv.h = L0, cm.ctx
+                    d1 = lv.to_device(np.ones(1))
+                    rc = L0.phip_comm_allreduce(cm.hip_comm(), d1, 1, 0)
+                    got = lv.to_host(d1, 1)[0] if not rc else -1.0
+                    lv.free(d1)
+                    if rc or got != world:
+                        raise RuntimeError("trial ncclAllReduce gave %r: %s" % (got, L0.phip_last_error().decode()))
+                one = np.ones(1)
+                if L0.phip_comm_allreduce_host(cm.hip_comm(), one.ctypes.data_as(C.POINTER(C.c_double)), 1, 0) or one[0] != world:
+                    raise RuntimeError("trial sum over the ranks gave %r: %s" % (one[0], L0.phip_last_error().decode()))
+            except Exception as e:
+                why = "rank %d: %s" % (rank, e)
+            whys = [None] * world
+            dist.all_gather_object(whys, why)
+            bad = [w for w in whys if w]
+            if bad:
+                if cm is not None and not why:
+                    try:
+                        cm.finalize()
+                    except Exception:
+                        pass
+                return None, bad[0]
+            return cm, ""
+
+        L0 = capi.load()
+        comm, fell_back = make_comm(backend)
+        if comm is None and backend == "rccl":
+            # RCCL did not come up (reported in multi_gpu.backend_fallback): the ghost exchange and the sums over the ranks staged
+            # through host shared memory still give a measurement of the same job, one rank per GPU
+            if rank == 0:
+                sys.stderr.write("bench: RCCL backend failed (%s); falling back to the host-staged backend\n" % fell_back)
+            backend = "shm"
+            comm, why2 = make_comm(backend)
+            if comm is None:
+                raise SystemExit("no communicator: rccl: %s; shm: %s" % (fell_back, why2))
+        elif comm is None:
+            raise SystemExit("no communicator: %s: %s" % (backend, fell_back))
+        else:
+            fell_back = ""
     else:
         comm = P.Comm(device=0, backend="self")
     L = capi.load()
@@ -472,7 +524,7 @@ def main():
             L.phip_comm_rank_size(hc, C.byref(rr), C.byref(ss))
             ipcn = C.c_ulonglong()
             L.phip_halo_ipc_count(C.byref(ipcn))
-            out["multi_gpu"] = {"backend": backend, "rccl_ranks": ss.value if backend == "rccl" else 0, "comm_ranks": ss.value, "halo_rank0": halo,
+            out["multi_gpu"] = {"backend": backend, "backend_fallback": ("rccl failed: " + fell_back) if fell_back else None, "rccl_ranks": ss.value if backend == "rccl" else 0, "comm_ranks": ss.value, "halo_rank0": halo,
                                 "ghost_exchange": "peer writes into hipIpc-mapped receive buffers (PHIP_HALO_IPC=1)" if ipcn.value else
                                 ("grouped ncclSend/ncclRecv on a second stream" if backend == "rccl" else "staged through host shared memory (rehearsal backend)"),
                                 "reductions": "host shared-memory ring" if not os.environ.get("PETSCHIP_DEVICE_ALLREDUCE") else "ncclAllReduce"}
