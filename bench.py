@@ -400,7 +400,7 @@ def main():
         A = P.Mat.seqaij_with_arrays(comm, m, m, ai, aj, aa)
         nzA, nzB, mB = nz_local, 0, 0
     setup_s = time.time() - t0
-    keep_host_csr = world == 1 and rank == 0 and not a.no_cpu_baseline
+    keep_host_csr = (world == 1 and rank == 0 and not a.no_cpu_baseline) or world > 1  # N > 1: for the check of the distributed MatMult below
     if not keep_host_csr:
         del ai, aj, aa
     x, b = A.create_vecs()
@@ -460,6 +460,24 @@ def main():
         dy2 = y2.device_ptr()
         offd_us, _ = tm.kernel(lambda: L.phip_mat_multadd(hB, dl, dy2, dy2))
         lv.free(dl)
+    mm_check = None
+    if world > 1:
+        # the distributed MatMult (ghost exchange + both blocks) against numpy on this rank's rows, three different vectors in a row
+        # (a ghost value left over from the exchange before would show): the one place where this script sees the exchange between GPUs
+        errs = []
+        for k in range(3):
+            xg = np.cos(0.37 * (np.arange(N, dtype=np.float64) % 1013.0) + k)
+            x.set_array(xg[rs:rs + m])
+            A.mult(x, y2)
+            ref = np.add.reduceat(aa * xg[aj], ai[:-1].astype(np.int64))
+            ref[np.diff(ai) == 0] = 0.0
+            errs.append(float(np.abs(y2.array() - ref).max() / max(np.abs(ref).max(), 1e-300)))
+            del xg, ref
+        te = torch.tensor(errs, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        mm_check = {"max_rel_err_vs_numpy": [float(v) for v in te], "tolerance": 1e-12, "ok": bool(float(te.max()) <= 1e-12),
+                    "what": "MatMult_MPIAIJ of 3 different vectors in a row against numpy on every rank's rows, max over ranks"}
+        del ai, aj, aa
     y2.destroy()
     x.set_array(xsave)
     vk = vec_kernels(L, comm.ctx, tm, m, a.workload if world == 1 else "", incg_vec.get(2), incg_vec.get(3))
@@ -524,7 +542,7 @@ def main():
             L.phip_comm_rank_size(hc, C.byref(rr), C.byref(ss))
             ipcn = C.c_ulonglong()
             L.phip_halo_ipc_count(C.byref(ipcn))
-            out["multi_gpu"] = {"backend": backend, "backend_fallback": ("rccl failed: " + fell_back) if fell_back else None, "rccl_ranks": ss.value if backend == "rccl" else 0, "comm_ranks": ss.value, "halo_rank0": halo,
+            out["multi_gpu"] = {"backend": backend, "backend_fallback": ("rccl failed: " + fell_back) if fell_back else None, "matmult_check": mm_check, "rccl_ranks": ss.value if backend == "rccl" else 0, "comm_ranks": ss.value, "halo_rank0": halo,
                                 "ghost_exchange": "peer writes into hipIpc-mapped receive buffers (PHIP_HALO_IPC=1)" if ipcn.value else
                                 ("grouped ncclSend/ncclRecv on a second stream" if backend == "rccl" else "staged through host shared memory (rehearsal backend)"),
                                 "reductions": "host shared-memory ring" if not os.environ.get("PETSCHIP_DEVICE_ALLREDUCE") else "ncclAllReduce"}
