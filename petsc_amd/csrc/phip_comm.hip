@@ -741,11 +741,13 @@ static int halo_ipc_setup(phip_halo h)
   PHIP_CHECK_HIP(hipMalloc((void **)&h->ipc_sync, sizeof(unsigned long long) * nsync));
   PHIP_CHECK_HIP(hipMemset(h->ipc_sync, 0, sizeof(unsigned long long) * nsync));
   PHIP_CHECK_HIP(hipDeviceSynchronize()); /* hipMemset of device memory does not wait: the words must be zero before a neighbour can store into them */
-  struct Head { hipIpcMemHandle_t recv, sync; int32_t from_n, to_n, ok, pad; };
+  struct Head { hipIpcMemHandle_t recv, sync; int32_t from_n, to_n, ok, pad; char busid[32]; };
   std::vector<unsigned char> rec(sizeof(Head) + sizeof(int32_t) * ((size_t)2 * h->from_n + 1 + (size_t)h->to_n));
   Head                       hd;
   memset(&hd, 0, sizeof(hd));
   hd.from_n = h->from_n; hd.to_n = h->to_n;
+  if (hipDeviceGetPCIBusId(hd.busid, (int)sizeof(hd.busid), ctx->device) != hipSuccess) hd.busid[0] = 0; /* which GPU the buffers live on */
+  hd.busid[sizeof(hd.busid) - 1] = 0;
   hd.ok = hipIpcGetMemHandle(&hd.recv, h->ipc_recv) == hipSuccess && hipIpcGetMemHandle(&hd.sync, h->ipc_sync) == hipSuccess;
   (void)hipGetLastError();
   memcpy(rec.data(), &hd, sizeof(hd));
@@ -766,6 +768,16 @@ static int halo_ipc_setup(phip_halo h)
     if (sync_of[(size_t)p]) return 0;
     Head q;
     memcpy(&q, all[(size_t)p].data(), sizeof(q));
+    /* a neighbour on another GPU of this process's view: its memory must be reachable from here BEFORE a kernel stores into it (an
+       unreachable address is a memory fault, not an error code) -- ask, and switch peer access on rather than rely on the lazy flag */
+    int pdev = -1;
+    if (q.busid[0] && hipDeviceGetByPCIBusId(&pdev, q.busid) == hipSuccess && pdev != ctx->device) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, ctx->device, pdev) != hipSuccess || !can) { (void)hipGetLastError(); return 3; }
+      const hipError_t e = hipDeviceEnablePeerAccess(pdev, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return 3; }
+    }
+    (void)hipGetLastError();
     if (hipIpcOpenMemHandle(&recv_of[(size_t)p], q.recv, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return 1; }
     h->ipc_opened.push_back(recv_of[(size_t)p]);
     if (hipIpcOpenMemHandle(&sync_of[(size_t)p], q.sync, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); sync_of[(size_t)p] = NULL; return 1; }
@@ -775,7 +787,7 @@ static int halo_ipc_setup(phip_halo h)
   int bad = 0;
   for (int i = 0; i < h->to_n && !bad; i++) { /* neighbour p receives from me: its plan says where */
     const int p = h->to_procs[(size_t)i];
-    if (map_peer(p)) { bad = 1; break; }
+    if ((bad = map_peer(p))) break;
     Head q;
     memcpy(&q, all[(size_t)p].data(), sizeof(q));
     const int32_t *pt = reinterpret_cast<const int32_t *>(all[(size_t)p].data() + sizeof(Head));
@@ -787,7 +799,7 @@ static int halo_ipc_setup(phip_halo h)
   }
   for (int j = 0; j < h->from_n && !bad; j++) { /* neighbour p sends to me: my acknowledgement goes behind its flags */
     const int p = h->from_procs[(size_t)j];
-    if (map_peer(p)) { bad = 1; break; }
+    if ((bad = map_peer(p))) break;
     Head q;
     memcpy(&q, all[(size_t)p].data(), sizeof(q));
     const int32_t *pt = reinterpret_cast<const int32_t *>(all[(size_t)p].data() + sizeof(Head));
@@ -801,7 +813,7 @@ static int halo_ipc_setup(phip_halo h)
   int32_t              mybad = bad;
   if ((rc = phip_comm_allgather_host(c, &mybad, bads.data(), sizeof(int32_t)))) return rc;
   for (int p = 0; p < c->size; p++)
-    if (bads[(size_t)p]) { h->ipc_why = bads[(size_t)p] == 1 ? "hipIpcOpenMemHandle failed on some rank" : "the plans of two neighbours do not match"; return 0; }
+    if (bads[(size_t)p]) { h->ipc_why = bads[(size_t)p] == 1 ? "hipIpcOpenMemHandle failed on some rank" : bads[(size_t)p] == 3 ? "two neighbours' GPUs have no peer access" : "the plans of two neighbours do not match"; return 0; }
   std::vector<int32_t> seg((size_t)h->nsend + 1, 0);
   for (int i = 0; i < h->to_n; i++) for (int32_t k = h->to_starts[(size_t)i]; k < h->to_starts[(size_t)i + 1]; k++) seg[(size_t)k] = i;
   PHIP_CHECK_HIP(hipMalloc((void **)&h->d_send_seg, sizeof(int32_t) * seg.size()));
