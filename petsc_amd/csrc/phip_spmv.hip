@@ -103,8 +103,7 @@ struct phip_mat_s {
   int32_t  R; /* stored rows */
   int32_t *d_rowptr, *d_ridx, *d_col;
   double  *d_val;
-  int32_t *d_blkrow;
-  uint8_t *d_blktpr;
+  int4    *d_blkrec; /* [nblocks + 1] {first row, rows | log2(threads per row) << 24, first nonzero, end}: all a workgroup needs of its block in one scalar load */
   int32_t  nblocks;
   int32_t  tpr_user;
   std::vector<int32_t> *h_rowptr, *h_blkrow;
@@ -215,10 +214,27 @@ __device__ __forceinline__ void st_result2(double *p, double a, double b, bool n
   else *reinterpret_cast<double2 *>(p) = make_double2(a, b);
 }
 
+/* sum += prod[j] for j = j0, j0 + STEP, ... below e, in that order; eight LDS reads are requested before the first is added (the plain
+   loop waits out one LDS latency per entry, and with rows of very different lengths in a block that wait is what the block's time is) */
+template <int STEP>
+__device__ __forceinline__ double lds_ordered_sum(const double *prod, int j0, int e, double sum)
+{
+  int j = j0;
+  for (; j + 7 * STEP < e; j += 8 * STEP) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = prod[j + u * STEP];
+#pragma unroll
+    for (int u = 0; u < 8; u++) sum += v[u];
+  }
+  for (; j < e; j += STEP) sum += prod[j];
+  return sum;
+}
+
 template <int TPR, bool DOT>
 __device__ __forceinline__ void spmv_reduce_rows(const double *prod, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx,
                                                  const double *__restrict__ yin, double *__restrict__ yout, int r0, int r1, int abase,
-                                                 bool add, bool cprow, const double *__restrict__ dotv, double &dacc)
+                                                 bool add, bool cprow, const double *__restrict__ dotv, double &dacc, int ps, int pe)
 {
   const int t = threadIdx.x;
   constexpr int RPP = PHIP_THREADS / TPR; /* rows per pass */
@@ -229,20 +245,21 @@ __device__ __forceinline__ void spmv_reduce_rows(const double *prod, const int32
     const int  r = r0 + p * RPP + t / TPR;
     const bool valid = r < r1;
     int        s = 0, e = 0;
-    if (valid) { s = rowptr[r] - abase; e = rowptr[r + 1] - abase; }
+    if (p == 0) { s = ps - abase; e = pe - abase; } /* requested by the kernel together with the block's stream */
+    else if (valid) { s = rowptr[r] - abase; e = rowptr[r + 1] - abase; }
+    if (!valid) s = e = 0;
     double sum = 0.0;
     int    rout = 0;
     if (TPR == 1) {
       if (valid) {
         rout = cprow ? ridx[r] : r;
         const double y0 = add ? yin[rout] : 0.0;
-        sum = y0;
-        for (int j = s; j < e; j++) sum += prod[j];
+        sum = lds_ordered_sum<1>(prod, s, e, y0);
         yout[rout] = sum;
         if (DOT) dacc += dotv[rout] * (add ? sum - y0 : sum);
       }
     } else {
-      for (int j = s + sub; j < e; j += TPR) sum += prod[j];
+      sum = lds_ordered_sum<TPR>(prod, s + sub, e, 0.0);
 #pragma unroll
       for (int o = TPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
       if (valid && sub == 0) {
@@ -258,7 +275,7 @@ __device__ __forceinline__ void spmv_reduce_rows(const double *prod, const int32
 /* DOT: also accumulate sum_i dotv[i] * (A x)_i (the increment, for MultAdd) and leave it where ctl says; the grid then strides over
    the row blocks with a capped number of workgroups (launch_spmv_t).  Without DOT the grid is one workgroup per row block. */
 template <bool DOT, bool NT>
-__global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(int32_t nblocks, const int32_t *__restrict__ blkrow, const uint8_t *__restrict__ blktpr,
+__global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(int32_t nblocks, const int4 *__restrict__ blkrec,
                                                                      const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx,
                                                                      const int32_t *__restrict__ col, const double *__restrict__ val,
                                                                      const double *__restrict__ x, const double *__restrict__ yin,
@@ -268,13 +285,29 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(int32_t nbl
   const int t = threadIdx.x;
   double    dacc = 0.0;
   for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
-    const int r0 = blkrow[b], r1 = blkrow[b + 1];
-    const int base = rowptr[r0], end = rowptr[r1];
+    const int4 rec = blkrec[b]; /* one scalar load instead of the chain blkrow -> rowptr -> (after the barrier) blktpr */
+    const int  r0 = rec.x, r1 = rec.x + (rec.y & 0xffffff), tprl = (int)((unsigned)rec.y >> 24);
+    const int  base = rec.z, end = rec.w;
 
     if (end - base > SPMV_CAP) {
       /* one long row (the plan guarantees r1 == r0 + 1): whole workgroup strides over it */
-      double sum = 0.0;
-      for (int j = base + t; j < end; j += PHIP_THREADS) sum += val[j] * x[col[j]];
+      /* eight entries a thread requested together (columns, values, then the eight gathers), added in the order of the plain loop */
+      double        sum = 0.0;
+      constexpr int LU = 8;
+      for (int j0 = base + t; j0 < end; j0 += LU * PHIP_THREADS) {
+        int    cj[LU];
+        double vj[LU], xj[LU];
+#pragma unroll
+        for (int u = 0; u < LU; u++) {
+          const int j = j0 + u * PHIP_THREADS;
+          cj[u] = j < end ? col[j] : col[base];
+          vj[u] = j < end ? val[j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < LU; u++) xj[u] = x[cj[u]];
+#pragma unroll
+        for (int u = 0; u < LU; u++) if (j0 + u * PHIP_THREADS < end) sum += vj[u] * xj[u];
+      }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
       if ((t & 63) == 0) prod[t >> 6] = sum;
@@ -289,38 +322,41 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(int32_t nbl
     } else {
       /* phase 1: stream products into LDS.  abase is even so val pairs are 16-byte aligned. */
       const int abase = base & ~1;
-      double2   a[4];
+      /* the bounds of the row this thread sums first (row r0 + t / threads per row; clamped: a thread without a row ignores them) */
+      const int rfirst = min(r0 + (t >> tprl), r1 - 1);
+      const int ps = rowptr[rfirst], pe = rowptr[rfirst + 1];
+      if (end > base) { /* (a block of empty rows has no products, and x may be null for a matrix without nonzeros) */
+      double2   a[4], g[4];
       int2      c[4];
-      bool      v[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int e = abase + 2 * (t + k * PHIP_THREADS);
-        v[k] = e < end;
-        if (v[k]) {
-          a[k] = ld_stream<NT>(reinterpret_cast<const double2 *>(val + e));
-          c[k] = ld_stream<NT>(reinterpret_cast<const int2 *>(col + e));
-        }
+      for (int k = 0; k < 4; k++) { /* a pair behind the block's end repeats the block's first pair: no test, its product is never read */
+        const int e = abase + 2 * (t + k * PHIP_THREADS), ec = e < end ? e : abase;
+        a[k] = ld_stream<NT>(reinterpret_cast<const double2 *>(val + ec));
+        c[k] = ld_stream<NT>(reinterpret_cast<const int2 *>(col + ec));
       }
+      /* the eight stream loads and then the eight gathers of a thread are requested together: inside a test per pair, each pair
+         waited for its own loads (four memory round trips a block for the stream and four for the gathers instead of one each) */
+#pragma unroll
+      for (int k = 0; k < 4; k++) { g[k].x = x[c[k].x]; g[k].y = x[c[k].y]; }
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        if (v[k]) {
-          double2 p;
-          p.x = a[k].x * x[c[k].x];
-          p.y = a[k].y * x[c[k].y];
-          *reinterpret_cast<double2 *>(prod + 2 * (t + k * PHIP_THREADS)) = p;
-        }
+        double2 p;
+        p.x = a[k].x * g[k].x;
+        p.y = a[k].y * g[k].y;
+        *reinterpret_cast<double2 *>(prod + 2 * (t + k * PHIP_THREADS)) = p;
+      }
       }
       __syncthreads();
 
       /* phase 2: per-row sums out of LDS */
-      switch (blktpr[b]) {
-      case 0: spmv_reduce_rows<1, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc); break;
-      case 1: spmv_reduce_rows<2, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc); break;
-      case 2: spmv_reduce_rows<4, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc); break;
-      case 3: spmv_reduce_rows<8, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc); break;
-      case 4: spmv_reduce_rows<16, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc); break;
-      case 5: spmv_reduce_rows<32, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc); break;
-      default: spmv_reduce_rows<64, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc); break;
+      switch (tprl) {
+      case 0: spmv_reduce_rows<1, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc, ps, pe); break;
+      case 1: spmv_reduce_rows<2, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc, ps, pe); break;
+      case 2: spmv_reduce_rows<4, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc, ps, pe); break;
+      case 3: spmv_reduce_rows<8, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc, ps, pe); break;
+      case 4: spmv_reduce_rows<16, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc, ps, pe); break;
+      case 5: spmv_reduce_rows<32, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc, ps, pe); break;
+      default: spmv_reduce_rows<64, DOT>(prod, rowptr, ridx, yin, yout, r0, r1, abase, add, cprow, dotv, dacc, ps, pe); break;
       }
     }
     if (DOT) __syncthreads(); /* the next row block of this workgroup reuses prod[] */
@@ -1070,13 +1106,12 @@ __device__ __forceinline__ void wave_reduce_rows(const double *prod, int rpl, in
       if (valid) {
         const int    rout = cprow ? ridx[r] : r;
         const double y0 = add ? yin[rout] : 0.0;
-        sum = y0;
-        for (int j = s; j < e; j++) sum += prod[j];
+        sum = lds_ordered_sum<1>(prod, s, e, y0);
         yout[rout] = sum;
         if (DOT) dacc += dotv[rout] * (add ? sum - y0 : sum);
       }
     } else {
-      for (int j = s + sub; j < e; j += TPR) sum += prod[j];
+      sum = lds_ordered_sum<TPR>(prod, s + sub, e, 0.0);
 #pragma unroll
       for (int o = TPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
       if (valid && sub == 0) {
@@ -1135,7 +1170,13 @@ __global__ __launch_bounds__(LDSK_THREADS) void spmv_wave_lds_kernel(int32_t nwb
   __syncthreads();
   double *prod = lds_all + Kpad + w * WB_STAGE;
   double  dacc = 0.0;
-  auto    X = [&](int c) -> double { return c < K ? lds_all[c] : xcold[c - coff]; };
+  /* both sources are read by every lane, without a test (a hot lane asks the cold side for its first entry, a cold lane LDS for slot 0),
+     and the value is selected afterwards: with a branch per gather the wave waited for each cold load on its own */
+  auto    X = [&](int c) -> double {
+    const bool   hot = c < K;
+    const double vl = lds_all[hot ? c : 0], vg = xcold[hot ? 0 : c - coff];
+    return hot ? vl : vg;
+  };
   for (int b = gw; b < nwb; b += nw) {
     if (b + nw < nwb) wave_block_request<NT>(nxt, b + nw, wblkrow, wbase, wblktpr, rowptr, lcol, val, lane);
     if (cur.end - cur.base > WB_CAP) { /* one long row (the plan guarantees r1 == r0 + 1): the wave strides over it */
@@ -1970,12 +2011,14 @@ static int upload_plan(phip_mat A)
   build_plan(*A->h_rowptr, A->R, A->tpr_user, *A->h_blkrow, *A->h_blktpr);
   A->nblocks = (int32_t)A->h_blktpr->size();
   if (A->ctx->device < 0) return 0; /* planning-only: the plan stays on the host */
-  if (A->d_blkrow) { hipFree(A->d_blkrow); A->d_blkrow = NULL; }
-  if (A->d_blktpr) { hipFree(A->d_blktpr); A->d_blktpr = NULL; }
-  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_blkrow, sizeof(int32_t) * ((size_t)A->nblocks + 1)));
-  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_blktpr, (size_t)A->nblocks + 16));
-  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_blkrow, A->h_blkrow->data(), sizeof(int32_t) * ((size_t)A->nblocks + 1), hipMemcpyHostToDevice, A->ctx->stream));
-  if (A->nblocks) PHIP_CHECK_HIP(hipMemcpyAsync(A->d_blktpr, A->h_blktpr->data(), (size_t)A->nblocks, hipMemcpyHostToDevice, A->ctx->stream));
+  if (A->d_blkrec) { hipFree(A->d_blkrec); A->d_blkrec = NULL; }
+  std::vector<int4> rec((size_t)A->nblocks + 1, make_int4(0, 0, 0, 0));
+  for (int32_t b = 0; b < A->nblocks; b++) {
+    const int32_t r0 = (*A->h_blkrow)[(size_t)b], r1 = (*A->h_blkrow)[(size_t)b + 1];
+    rec[(size_t)b] = make_int4(r0, (r1 - r0) | ((int32_t)(*A->h_blktpr)[(size_t)b] << 24), (*A->h_rowptr)[(size_t)r0], (*A->h_rowptr)[(size_t)r1]);
+  }
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_blkrec, sizeof(int4) * rec.size()));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_blkrec, rec.data(), sizeof(int4) * rec.size(), hipMemcpyHostToDevice, A->ctx->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(A->ctx->stream));
   return 0;
 }
@@ -2240,7 +2283,7 @@ extern "C" int phip_mat_destroy(phip_mat A)
   free_hot(A);
   free_lds(A);
   delete A->h_sptr;
-  hipFree(A->d_rowptr); hipFree(A->d_ridx); hipFree(A->d_col); hipFree(A->d_val); hipFree(A->d_blkrow); hipFree(A->d_blktpr);
+  hipFree(A->d_rowptr); hipFree(A->d_ridx); hipFree(A->d_col); hipFree(A->d_val); hipFree(A->d_blkrec);
   delete A->h_rowptr; delete A->h_blkrow; delete A->h_blktpr;
   delete A;
   return 0;
@@ -2408,10 +2451,10 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
       cols = A->d_hcol; xs = A->d_hx;
     }
     if (csr_nt)
-      hipLaunchKernelGGL((spmv_rowblock_kernel<DOT, true>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->nblocks, A->d_blkrow, A->d_blktpr, A->d_rowptr, A->d_ridx, cols,
+      hipLaunchKernelGGL((spmv_rowblock_kernel<DOT, true>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->nblocks, A->d_blkrec, A->d_rowptr, A->d_ridx, cols,
                          A->d_val, xs, d_yin, d_yout, add, A->use_cprow, d_v, ctl);
     else
-      hipLaunchKernelGGL((spmv_rowblock_kernel<DOT, false>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->nblocks, A->d_blkrow, A->d_blktpr, A->d_rowptr, A->d_ridx, cols,
+      hipLaunchKernelGGL((spmv_rowblock_kernel<DOT, false>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->nblocks, A->d_blkrec, A->d_rowptr, A->d_ridx, cols,
                          A->d_val, xs, d_yin, d_yout, add, A->use_cprow, d_v, ctl);
   }
   PHIP_CHECK_HIP(hipGetLastError());

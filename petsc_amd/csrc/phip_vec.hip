@@ -350,10 +350,13 @@ __global__ __launch_bounds__(PHIP_THREADS) void ew_batch_kernel(int32_t n, EwBat
    requested together, the new R goes to the product through a register, and nothing is read twice.  Same expressions (ew_apply), same
    entry order per thread, same grid: the bits of the generic kernel.  RFIRST: the product was called as Z = R .* D, else Z = D .* R.
    Z may be W (KSPCG keeps both in one work vector, cg.c:106: W = Z): a thread has read its entries of W before it stores them as Z. */
-template <bool RFIRST, bool WITHX = true>
+template <bool RFIRST, bool WITHX = true, int NTC = -1>
 __global__ __launch_bounds__(PHIP_THREADS) void cg_update_kernel(int32_t n, double *__restrict__ x, const double *__restrict__ p, double a, double *__restrict__ r,
-                                                                 const double *w, double b, double *z, const double *__restrict__ d, RedCtl ctl, int nt)
+                                                                 const double *w, double b, double *z, const double *__restrict__ d, RedCtl ctl, int nt_arg)
 {
+  /* NTC >= 0: the cache hints are compile-time (the two settings in use, 0 and 7): with the hint tested per load at run time the loads
+     of a thread's second entry pair waited for those of the first (s_waitcnt vmcnt(0) between them in the plain-load path) */
+  const int nt = NTC >= 0 ? NTC : nt_arg;
   __shared__ double lds[12];
   double            acc[3] = {0.0, 0.0, 0.0};
   const int64_t     n2 = n >> 1;
@@ -405,8 +408,10 @@ __global__ __launch_bounds__(PHIP_THREADS) void cg_update_kernel(int32_t n, doub
 
 /* The pair that KSPCG leaves when its VecAXPY(X,a,P) stays behind (see phip_vec_pointwise_mult_reduce): VecAXPY(X,a,P); VecAYPX(P,b,Z)
    (cg.c:222 and, in the next iteration, cg.c:202).  P is read once for both; same expressions and entry order as the single kernels. */
-__global__ __launch_bounds__(PHIP_THREADS) void xp_update_kernel(int32_t n, double *__restrict__ x, double *__restrict__ p, double a, const double *__restrict__ z, double b, int nt)
+template <int NTC>
+__global__ __launch_bounds__(PHIP_THREADS) void xp_update_kernel(int32_t n, double *__restrict__ x, double *__restrict__ p, double a, const double *__restrict__ z, double b, int nt_arg)
 {
+  const int     nt = NTC >= 0 ? NTC : nt_arg; /* as in cg_update_kernel */
   const int64_t n2 = n >> 1;
   const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
   constexpr int UN = 2;
@@ -541,8 +546,10 @@ static int ew_flush_launch(phip_ctx c, int nops)
 {
   if (nops == 1) return ew_launch_single(c, c->ew_len, c->ew[0]);
   if (nops == 2 && xp_update_shape(c->ew[0], c->ew[1])) {
-    hipLaunchKernelGGL(xp_update_kernel, dim3(EW_GRID(c->ew_len)), dim3(PHIP_THREADS), 0, c->stream, c->ew_len, c->ew[0].out, c->ew[1].out, c->ew[0].a, c->ew[1].x, c->ew[1].a,
-                       ew_nt(c->ew_len));
+    const int ntv = ew_nt(c->ew_len);
+#define XP_LAUNCH(NTC) hipLaunchKernelGGL((xp_update_kernel<NTC>), dim3(EW_GRID(c->ew_len)), dim3(PHIP_THREADS), 0, c->stream, c->ew_len, c->ew[0].out, c->ew[1].out, c->ew[0].a, c->ew[1].x, c->ew[1].a, ntv)
+    if (ntv == 0) XP_LAUNCH(0); else if (ntv == 7) XP_LAUNCH(7); else XP_LAUNCH(-1);
+#undef XP_LAUNCH
     PHIP_CHECK_HIP(hipGetLastError());
     return 0;
   }
@@ -692,20 +699,22 @@ extern "C" int phip_vec_pointwise_mult_reduce(phip_ctx c, int32_t n, double *d_w
        device-pointer getters of the glue) launches what is pending first.  PHIP_CG_DEFER_X=0 / phip_set_cg_defer_x(0) switches it off. */
     if (g_defer_x < 0) g_defer_x = getenv("PHIP_CG_DEFER_X") ? (atoi(getenv("PHIP_CG_DEFER_X")) != 0) : 1;
     if (shape && g_defer_x) {
-      if (shape == 2)
-        hipLaunchKernelGGL((cg_update_kernel<true, false>), grid, dim3(PHIP_THREADS), 0, c->stream, n, (double *)NULL, (const double *)NULL, 0.0, B.op[1].out, B.op[1].x, B.op[1].a, d_w, d_y, ctl, ew_nt(n));
-      else
-        hipLaunchKernelGGL((cg_update_kernel<false, false>), grid, dim3(PHIP_THREADS), 0, c->stream, n, (double *)NULL, (const double *)NULL, 0.0, B.op[1].out, B.op[1].x, B.op[1].a, d_w, d_x, ctl, ew_nt(n));
+      const int ntv = ew_nt(n);
+#define CGU_LAUNCH(RF, NTC, DD) hipLaunchKernelGGL((cg_update_kernel<RF, false, NTC>), grid, dim3(PHIP_THREADS), 0, c->stream, n, (double *)NULL, (const double *)NULL, 0.0, B.op[1].out, B.op[1].x, B.op[1].a, d_w, DD, ctl, ntv)
+      if (shape == 2) { if (ntv == 0) CGU_LAUNCH(true, 0, d_y); else if (ntv == 7) CGU_LAUNCH(true, 7, d_y); else CGU_LAUNCH(true, -1, d_y); }
+      else { if (ntv == 0) CGU_LAUNCH(false, 0, d_x); else if (ntv == 7) CGU_LAUNCH(false, 7, d_x); else CGU_LAUNCH(false, -1, d_x); }
+#undef CGU_LAUNCH
       PHIP_CHECK_HIP(hipGetLastError());
       if (e1) PHIP_CHECK_HIP(hipEventRecord(e1, c->stream));
       c->ew[0] = B.op[0];
       c->ew_n = 1;
       return 0;
     }
-    if (shape == 2)
-      hipLaunchKernelGGL((cg_update_kernel<true>), grid, dim3(PHIP_THREADS), 0, c->stream, n, B.op[0].out, B.op[0].x, B.op[0].a, B.op[1].out, B.op[1].x, B.op[1].a, d_w, d_y, ctl, ew_nt(n));
-    else if (shape == 1)
-      hipLaunchKernelGGL((cg_update_kernel<false>), grid, dim3(PHIP_THREADS), 0, c->stream, n, B.op[0].out, B.op[0].x, B.op[0].a, B.op[1].out, B.op[1].x, B.op[1].a, d_w, d_x, ctl, ew_nt(n));
+    const int ntv = ew_nt(n);
+#define CGU_LAUNCH(RF, NTC, DD) hipLaunchKernelGGL((cg_update_kernel<RF, true, NTC>), grid, dim3(PHIP_THREADS), 0, c->stream, n, B.op[0].out, B.op[0].x, B.op[0].a, B.op[1].out, B.op[1].x, B.op[1].a, d_w, DD, ctl, ntv)
+    if (shape == 2) { if (ntv == 0) CGU_LAUNCH(true, 0, d_y); else if (ntv == 7) CGU_LAUNCH(true, 7, d_y); else CGU_LAUNCH(true, -1, d_y); }
+    else if (shape == 1) { if (ntv == 0) CGU_LAUNCH(false, 0, d_x); else if (ntv == 7) CGU_LAUNCH(false, 7, d_x); else CGU_LAUNCH(false, -1, d_x); }
+#undef CGU_LAUNCH
     else
       hipLaunchKernelGGL((ew_batch_kernel<true>), grid, dim3(PHIP_THREADS), 0, c->stream, n, B, ctl);
     PHIP_CHECK_HIP(hipGetLastError());
