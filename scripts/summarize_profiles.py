@@ -19,8 +19,8 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 # bench.py kernel label -> prefix of the demangled kernel name the counters are taken from (the variant the back-to-back timing launches)
 WANT = {
-    "box27_256": {"spmv_dmaskg_kernel": "void spmv_dmaskg_kernel<false", "cg_update_kernel": "void cg_update_kernel", "xp_update_kernel": "xp_update_kernel"},
-    "lap7_128": {"spmv_dmask4_kernel": "void spmv_dmask4_kernel<false", "cg_update_kernel": "void cg_update_kernel", "xp_update_kernel": "xp_update_kernel"},
+    "box27_256": {"spmv_dmaskg_kernel": "void spmv_dmaskg_kernel<false", "cg_update_kernel": "void cg_update_kernel", "xp_update_kernel": "void xp_update_kernel"},
+    "lap7_128": {"spmv_dmask4_kernel": "void spmv_dmask4_kernel<false", "cg_update_kernel": "void cg_update_kernel", "xp_update_kernel": "void xp_update_kernel"},
     "lap7_256_var": {"spmv_sell_kernel": "void spmv_sell_kernel", "spmv_rowblock_kernel": "void spmv_rowblock_kernel"},
 }
 
