@@ -1137,17 +1137,16 @@ __device__ __forceinline__ void wave_block_request(WaveBlock &B, int b, const in
                                                    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ lcol, const double *__restrict__ val, int lane)
 {
   B.r0 = wblkrow[b]; B.r1 = wblkrow[b + 1]; B.base = wbase[b]; B.end = wbase[b + 1]; B.tpr = wblktpr[b];
-  B.rpl = (lane < B.r1 - B.r0) ? rowptr[B.r0 + lane] : B.end;
-  if (B.end - B.base > WB_CAP) return; /* a long row: streamed when its turn comes */
-  const int abase = B.base & ~1;     /* value pairs are 16-byte aligned */
+  /* no tests around the loads (a test makes the wave wait for the load inside it -- the request would not run ahead of anything):
+     a lane behind the block's rows reads rowptr[r1] = end, a pair behind its end repeats the block's first pair */
+  const int nr = B.r1 - B.r0;
+  B.rpl = rowptr[B.r0 + (lane < nr ? lane : nr)];
+  const int abase = B.base & ~1; /* value pairs are 16-byte aligned */
 #pragma unroll
   for (int k = 0; k < 2; k++) {
-    const int e = abase + 2 * (lane + 64 * k);
-    B.a[k] = make_double2(0.0, 0.0); B.c[k] = make_int2(0, 0);
-    if (e < B.end) {
-      B.a[k] = ld_stream<NT>(reinterpret_cast<const double2 *>(val + e));
-      B.c[k] = ld_stream<NT>(reinterpret_cast<const int2 *>(lcol + e));
-    }
+    const int e = abase + 2 * (lane + 64 * k), ec = (e < B.end && B.end - B.base <= WB_CAP) ? e : abase;
+    B.a[k] = ld_stream<NT>(reinterpret_cast<const double2 *>(val + ec));
+    B.c[k] = ld_stream<NT>(reinterpret_cast<const int2 *>(lcol + ec));
   }
 }
 
@@ -1180,8 +1179,22 @@ __global__ __launch_bounds__(LDSK_THREADS) void spmv_wave_lds_kernel(int32_t nwb
   for (int b = gw; b < nwb; b += nw) {
     if (b + nw < nwb) wave_block_request<NT>(nxt, b + nw, wblkrow, wbase, wblktpr, rowptr, lcol, val, lane);
     if (cur.end - cur.base > WB_CAP) { /* one long row (the plan guarantees r1 == r0 + 1): the wave strides over it */
-      double sum = 0.0;
-      for (int j = cur.base + lane; j < cur.end; j += 64) sum += val[j] * X(lcol[j]);
+      double        sum = 0.0;
+      constexpr int LU = 8; /* eight entries a lane requested together, added in the order of the plain loop */
+      for (int j0 = cur.base + lane; j0 < cur.end; j0 += LU * 64) {
+        int    cj[LU];
+        double vj[LU], xj[LU];
+#pragma unroll
+        for (int u = 0; u < LU; u++) {
+          const int j = j0 + u * 64, jc = j < cur.end ? j : cur.base;
+          cj[u] = lcol[jc];
+          vj[u] = val[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < LU; u++) xj[u] = X(cj[u]);
+#pragma unroll
+        for (int u = 0; u < LU; u++) if (j0 + u * 64 < cur.end) sum += vj[u] * xj[u];
+      }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
       if (lane == 0) {
@@ -1192,14 +1205,15 @@ __global__ __launch_bounds__(LDSK_THREADS) void spmv_wave_lds_kernel(int32_t nwb
       }
     } else {
       const int abase = cur.base & ~1;
+      double2 g[2];
 #pragma unroll
-      for (int k = 0; k < 2; k++) {
-        if (abase + 2 * (lane + 64 * k) < cur.end) {
-          double2 p;
-          p.x = cur.a[k].x * X(cur.c[k].x);
-          p.y = cur.a[k].y * X(cur.c[k].y);
-          *reinterpret_cast<double2 *>(prod + 2 * (lane + 64 * k)) = p;
-        }
+      for (int k = 0; k < 2; k++) { g[k].x = X(cur.c[k].x); g[k].y = X(cur.c[k].y); } /* the four gathers of a lane together */
+#pragma unroll
+      for (int k = 0; k < 2; k++) { /* a pair behind the block's end leaves a product nobody reads */
+        double2 p;
+        p.x = cur.a[k].x * g[k].x;
+        p.y = cur.a[k].y * g[k].y;
+        *reinterpret_cast<double2 *>(prod + 2 * (lane + 64 * k)) = p;
       }
       /* the wave's own stage: its LDS accesses execute in order, the fences only keep the compiler from moving them */
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1316,7 +1330,8 @@ static int setup_hot(phip_mat A, const int32_t *h_j, std::vector<int32_t> &order
 /* ---- hot columns in LDS: set-up (spmv_wave_lds_kernel) ---------------------------------------------------------------------------
    OFF BY DEFAULT (PHIP_LDS_HOT / phip_set_default_lds_hot: 0 never = default, 1 by the rule below, 2 whenever the matrix has nonzeros).
    Measured on MI355X, R-MAT (profiles/r02_exp_rmat_lds.jsonl): scale 20 (57.6 % of the nonzeros in the K = 16 256 columns LDS holds)
-   391 us against 123 us for the row-block kernel, scale 22 (40.6 %) 1543 against 479 us -- the few rows with tens of thousands of
+   391 us against 123 us for the row-block kernel, scale 22 (40.6 %) 1543 against 479 us (later, both kernels without tests around their
+   loads and long rows eight entries a lane: 170 against 89 us, 843 against 473 us) -- the few rows with tens of thousands of
    nonzeros are walked by ONE wave each; with every row cut to 254 nonzeros 68.9 against 71.6 us: even then, with two thirds of the
    gathers out of LDS, the kernel only draws level, because 16 waves a CU (what one 1024-thread workgroup per CU leaves) cannot hide
    the chain stream -> gather -> stage -> row sums of a 254-nonzero block, requesting the next block's stream one block ahead
