@@ -178,6 +178,15 @@ def test_spmv_long_rows_and_edges(ctx, orc):
     assert len(gpu_mult(ctx, np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0), 0, np.zeros(1))) == 0
     y = gpu_mult(ctx, np.zeros(6, np.int32), np.zeros(0, np.int32), np.zeros(0), 5, np.ones(5))
     np.testing.assert_array_equal(y, np.zeros(5))
+    # no columns at all and a null x (allowed when there are no nonzeros): the row-block kernel must not gather anything
+    A = ctx.mat_create(5, 0, np.zeros(6, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    dy = ctx.to_device(np.full(5, 7.0))
+    ctx.check(ctx.lib.phip_mat_mult(A, None, dy))
+    np.testing.assert_array_equal(ctx.to_host(dy, 5), np.zeros(5))
+    dz = ctx.to_device(np.arange(5.0))
+    ctx.check(ctx.lib.phip_mat_multadd(A, None, dz, dy))
+    np.testing.assert_array_equal(ctx.to_host(dy, 5), np.arange(5.0))
+    ctx.free(dy); ctx.free(dz); ctx.check(ctx.lib.phip_mat_destroy(A))
 
 
 def test_spmv_compressed_row(ctx, orc):
