@@ -762,6 +762,61 @@ def test_full_size_properties(orc):
     assert run_ranks(1, body)[0]
 
 
+def test_full_size_config3(orc):
+    """BASELINE config 3 at full size -- the bench's north-star workload: 27-point box stencil on 256^3 (16.8 M rows, 449 M nonzeros)
+    through the default layout (diagonal masks, group descriptors).  Size-independent properties of the product (linearity, symmetry,
+    a strided sample of rows against numpy), MatGetDiagonal, and 12 iterations of KSPCG + PCJACOBI against the oracle on the same
+    system: same iteration count and reason, residual history within 1e-9, final residual within 1e-10 (the north star's bar)."""
+    from petsc_amd import generators as G, petsc as P
+    nn = 256
+    n = nn ** 3
+    ai, aj, aa = G.stencil_rows_native(27, nn, nn, nn, 0, n)
+    assert len(aj) == 449455096
+    rng = np.random.default_rng(3)
+    xa, xb = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    b = rng.uniform(-1, 1, n)
+    its = 12
+
+    def body(comm):
+        A = P.Mat.seqaij_with_arrays(comm, n, n, ai, aj, aa)
+        x, y = A.create_vecs()
+        outs = []
+        for v in (xa, xb, 2.0 * xa - 3.0 * xb):
+            x.set_array(v)
+            A.mult(x, y)
+            outs.append(y.array())
+        ya, yb, yc = outs
+        assert np.abs(yc - (2.0 * ya - 3.0 * yb)).max() <= 1e-12 * np.abs(yc).max()
+        assert abs(xb @ ya - xa @ yb) <= 1e-12 * np.abs(xb * ya).sum()  # symmetric matrix
+        rows = np.concatenate([np.arange(0, n, 40009), [n - 1, n - nn, nn * nn - 1, nn * nn]])
+        ref = np.array([np.dot(aa[ai[r]:ai[r + 1]], xa[aj[ai[r]:ai[r + 1]]]) for r in rows])
+        assert np.abs(ya[rows] - ref).max() <= 1e-12 * np.abs(ref).max()
+        d = x.duplicate()
+        A.get_diagonal(d)
+        dref = np.array([aa[ai[r]:ai[r + 1]][aj[ai[r]:ai[r + 1]] == r][0] for r in rows])
+        np.testing.assert_array_equal(d.array()[rows], dref)
+        bv = P.Vec.from_array(comm, b, n)
+        ksp = P.KSP(comm, "cg", "jacobi")
+        ksp.set_operators(A)
+        ksp.set_tolerances(rtol=1e-30, max_it=its)
+        ksp.set_residual_history()
+        x.set(0.0)
+        res = ksp.solve(bv, x)
+        res["x"] = x.array()
+        for o in (ksp, x, y, d, bv, A):
+            o.destroy()
+        return res
+
+    res = run_ranks(1, body)[0]
+    ref = orc.operator(ai, aj, aa, 1).solve(b, "cg", "jacobi", rtol=1e-30, max_it=its)
+    assert (res["its"], res["reason"]) == (ref["its"], ref["reason"]) and res["its"] == its
+    rn0 = ref["history"][0]
+    k = min(len(res["history"]), len(ref["history"]))
+    assert k >= its and np.abs(res["history"][:k] - ref["history"][:k]).max() <= 1e-9 * rn0
+    assert abs(res["rnorm"] - ref["rnorm"]) <= 1e-10 * rn0
+    assert np.abs(res["x"] - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
+
+
 @pytest.mark.parametrize("size", [1, 2, 3])
 def test_byproduct_cache(orc, size):
     """VecTDot(P,W) after MatMult(A,P,W), VecNorm(Z) and VecTDot(Z,R) after VecPointwiseMult(Z,R,D) are served from by-products
