@@ -817,6 +817,55 @@ def test_full_size_config3(orc):
     assert np.abs(res["x"] - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
 
 
+def test_full_size_config4(orc):
+    """BASELINE config 4 at full size: 3-D convection-diffusion 192^3 (7.08 M rows, 49.3 M nonzeros, nonsymmetric), KSPGMRES(30) +
+    PCJACOBI for 36 iterations (one restart) against the oracle on the same system: iteration count, reason, residual history within
+    1e-9 and final residual within 1e-10; the product on a strided sample of rows against numpy, and the transposed product through
+    (A^T x) . y = x . (A y)."""
+    from petsc_amd import generators as G, petsc as P
+    nn = 192
+    ai, aj, aa = G.convdiff3d_7pt(nn)
+    n = len(ai) - 1
+    assert (n, len(aj)) == (7077888, 49324032)
+    rng = np.random.default_rng(4)
+    xa, xb, b = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    its = 36
+
+    def body(comm):
+        A = P.Mat.seqaij_with_arrays(comm, n, n, ai, aj, aa)
+        x, y = A.create_vecs()
+        x.set_array(xa)
+        A.mult(x, y)
+        ya = y.array()
+        rows = np.concatenate([np.arange(0, n, 20011), [n - 1, nn * nn - 1, nn * nn]])
+        ref = np.array([np.dot(aa[ai[r]:ai[r + 1]], xa[aj[ai[r]:ai[r + 1]]]) for r in rows])
+        assert np.abs(ya[rows] - ref).max() <= 1e-12 * np.abs(ref).max()
+        x.set_array(xb)
+        A.mult_transpose(x, y)
+        assert abs(y.array() @ xa - xb @ ya) <= 1e-12 * np.abs(xb * ya).sum()
+        bv = P.Vec.from_array(comm, b, n)
+        ksp = P.KSP(comm, "gmres", "jacobi")
+        ksp.set_operators(A)
+        ksp.set_tolerances(rtol=1e-30, max_it=its)
+        ksp.gmres_set_restart(30)
+        ksp.set_residual_history()
+        x.set(0.0)
+        res = ksp.solve(bv, x)
+        res["x"] = x.array()
+        for o in (ksp, x, y, bv, A):
+            o.destroy()
+        return res
+
+    res = run_ranks(1, body)[0]
+    ref = orc.operator(ai, aj, aa, 1).solve(b, "gmres", "jacobi", rtol=1e-30, max_it=its, restart=30)
+    assert (res["its"], res["reason"]) == (ref["its"], ref["reason"]) and res["its"] == its
+    rn0 = ref["history"][0]
+    k = min(len(res["history"]), len(ref["history"]))
+    assert k >= its and np.abs(res["history"][:k] - ref["history"][:k]).max() <= 1e-9 * rn0
+    assert abs(res["rnorm"] - ref["rnorm"]) <= 1e-10 * rn0
+    assert np.abs(res["x"] - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
+
+
 @pytest.mark.parametrize("size", [1, 2, 3])
 def test_byproduct_cache(orc, size):
     """VecTDot(P,W) after MatMult(A,P,W), VecNorm(Z) and VecTDot(Z,R) after VecPointwiseMult(Z,R,D) are served from by-products
