@@ -817,6 +817,45 @@ def test_full_size_config3(orc):
     assert np.abs(res["x"] - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
 
 
+def test_full_size_config1(orc):
+    """BASELINE config 1 at full size: src/ksp/ksp/examples/tutorials/ex2.c with -m 1000 -n 1000 (2-D 5-point Laplacian, b = A 1,
+    KSPCG + PCJACOBI to rtol 1e-2 / ((m+1)(n+1))) against the oracle: iteration count within 1, same reason, and -- when the counts agree --
+    final residual within 1e-10 of the initial one; the error norm ex2 prints (|x - 1|) agrees to 1e-6."""
+    from petsc_amd import generators as G, petsc as P
+    mm = 1000
+    ai, aj, aa = G.laplace2d_5pt(mm, mm)
+    n = len(ai) - 1
+    rtol = 1e-2 / ((mm + 1) * (mm + 1))
+    bref = orc.operator(ai, aj, aa, 1).mult(np.ones(n))
+
+    def body(comm):
+        A = P.Mat.seqaij_with_arrays(comm, n, n, ai, aj, aa)
+        x, b = A.create_vecs()
+        x.set(1.0)
+        A.mult(x, b)
+        np.testing.assert_array_equal(b.array(), bref)
+        ksp = P.KSP(comm, "cg", "jacobi")
+        ksp.set_operators(A)
+        ksp.set_tolerances(rtol=rtol)
+        ksp.set_residual_history()
+        x.set(0.0)
+        res = ksp.solve(b, x)
+        res["x"] = x.array()
+        for o in (ksp, x, b, A):
+            o.destroy()
+        return res
+
+    res = run_ranks(1, body)[0]
+    ref = orc.operator(ai, aj, aa, 1).solve(bref, "cg", "jacobi", rtol=rtol)
+    assert res["reason"] == ref["reason"] and abs(res["its"] - ref["its"]) <= 1 and ref["its"] > 1000
+    rn0 = ref["history"][0]
+    if res["its"] == ref["its"]:
+        assert abs(res["rnorm"] - ref["rnorm"]) <= 1e-10 * rn0
+    k = min(len(res["history"]), len(ref["history"]), 200)
+    assert np.abs(res["history"][:k] - ref["history"][:k]).max() <= 1e-9 * rn0
+    assert abs(np.linalg.norm(res["x"] - 1.0) - np.linalg.norm(ref["x"] - 1.0)) <= 1e-6 * np.linalg.norm(ref["x"] - 1.0)
+
+
 def test_full_size_config4(orc):
     """BASELINE config 4 at full size: 3-D convection-diffusion 192^3 (7.08 M rows, 49.3 M nonzeros, nonsymmetric), KSPGMRES(30) +
     PCJACOBI for 36 iterations (one restart) against the oracle on the same system: iteration count, reason, residual history within
