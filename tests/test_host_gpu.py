@@ -730,8 +730,8 @@ def test_jacobi_variants(orc):
 
 
 def test_full_size_properties(orc):
-    """BASELINE config 2 at full size (128^3, 7-point): linearity and symmetry of the SpMV, and agreement with the oracle on
-    a strided sample of rows (the oracle computes only those rows)."""
+    """BASELINE config 2 at full size (128^3, 7-point): linearity and symmetry of the SpMV, agreement with the oracle on
+    a strided sample of rows (the oracle computes only those rows), and 40 KSPCG + PCJACOBI iterations against the oracle."""
     from petsc_amd import generators as G, petsc as P
     ai, aj, aa = G.laplace3d_7pt(128, dirichlet_rows=False)
     n = len(ai) - 1
@@ -755,11 +755,27 @@ def test_full_size_properties(orc):
         d = x.duplicate()
         A.get_diagonal(d)
         np.testing.assert_array_equal(d.array(), np.full(n, 6.0))
-        for o in (x, y, d, A):
+        bv = P.Vec.from_array(comm, xb, n)
+        ksp = P.KSP(comm, "cg", "jacobi")
+        ksp.set_operators(A)
+        ksp.set_tolerances(rtol=1e-30, max_it=40)
+        ksp.set_residual_history()
+        x.set(0.0)
+        res = ksp.solve(bv, x)
+        res["x"] = x.array()
+        for o in (ksp, bv, x, y, d, A):
             o.destroy()
-        return True
+        return res, xb
 
-    assert run_ranks(1, body)[0]
+    res, b = run_ranks(1, body)[0]
+    # 40 KSPCG + PCJACOBI iterations of the same system by the oracle
+    ref = orc.operator(ai, aj, aa, 1).solve(b, "cg", "jacobi", rtol=1e-30, max_it=40)
+    assert (res["its"], res["reason"]) == (ref["its"], ref["reason"]) and res["its"] == 40
+    rn0 = ref["history"][0]
+    k = min(len(res["history"]), len(ref["history"]))
+    assert k >= 40 and np.abs(res["history"][:k] - ref["history"][:k]).max() <= 1e-9 * rn0
+    assert abs(res["rnorm"] - ref["rnorm"]) <= 1e-10 * rn0
+    assert np.abs(res["x"] - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
 
 
 def test_full_size_config3(orc):
