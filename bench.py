@@ -230,6 +230,37 @@ def vec_kernels(L, ctx, tm, m, workload="", incg_batch=None, incg_xp=None):
     return out
 
 
+def rmat_leg(P, L, comm, tm, name, scale):
+    """single-GPU leg: SpMV of BASELINE config 5's matrix family (R-MAT, a,b,c,d = 0.57,0.19,0.19,0.05, 16 edges per row, duplicates summed) at a
+    scale that generates in seconds; the product is the CSR row-block kernel's (irregular matrices have no stencil layout)"""
+    from petsc_amd import generators as G
+    t0 = time.time()
+    ai, aj, aa = G.rmat(scale)
+    gen_s = time.time() - t0
+    m, nz = len(ai) - 1, int(ai[-1])
+    lens = np.diff(ai)
+    t0 = time.time()
+    A = P.Mat.seqaij_with_arrays(comm, m, m, ai, aj, aa)
+    setup_s = time.time() - t0
+    hA = A.device_mat(0)
+    x, y = A.create_vecs()
+    x.set_array(np.linspace(-1.0, 1.0, m))
+    dx, dy = x.device_ptr(), y.device_ptr()
+    per = [int(lens[(m * r) // 8:(m * (r + 1)) // 8].sum()) for r in range(8)]
+    out = {"matrix": "R-MAT scale %d (BASELINE config 5's generator; config 5 itself is scale 24)" % scale, "rows": m, "nnz": nz, "generate_s": round(gen_s, 1),
+           "setup_s": round(setup_s, 2), "max_row": int(lens.max()), "empty_rows": int((lens == 0).sum()),
+           "nnz_imbalance_8_row_blocks": round(max(per) / (nz / 8.0), 2)}
+    kernel, layout, real, alg = layout_of(L, hA, m, m, nz)
+    avg, pcts = tm.kernel(lambda: L.phip_mat_mult(hA, dx, dy))
+    out["roofline"] = roofline_obj(name, kernel, layout, real, alg, avg, pcts, resident_bytes=real)
+    out["gathers_per_s"] = round(nz / (avg * 1e-6))
+    out["bound_note"] = ("one divergent 8-byte gather per nonzero: the texture path serves about 210 G of them a second when every line is an L2 hit, "
+                         "and from about 4 M columns on a third of them miss L2 and fill a 128-byte line each (DESIGN.md section 3)")
+    for o in (x, y, A):
+        o.destroy()
+    return out
+
+
 def spmv_leg(P, L, comm, tm, name, kind, n, perturb, with_cg, steps, fmt_csr_too=False):
     """single-GPU leg: SpMV roofline of the layout the library picks (and, fmt_csr_too, of the CSR row-block kernel on the same matrix)"""
     t0 = time.time()
@@ -283,7 +314,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="box27_256")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
-    ap.add_argument("--legs", default="auto", help="auto (N=1: lap7_128,lap7_256_var) | none | comma-separated names")
+    ap.add_argument("--legs", default="auto", help="auto (N=1: lap7_128,lap7_256_var,rmat_22) | none | comma-separated names (lap7_<n>, box27_<n>, rmat_<scale>)")
     ap.add_argument("--ksp", default="cg", choices=["cg", "pipecg"], help="developer switch; the judged metric is KSPCG")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
@@ -543,7 +574,7 @@ def main():
     if rank == 0 and world == 1:
         legs = a.legs
         if legs == "auto":
-            legs = "lap7_128,lap7_256_var"
+            legs = "lap7_128,lap7_256_var,rmat_22"
         out["legs"] = {}
         for leg in [s for s in legs.split(",") if s and s != "none"]:
             if leg == "lap7_128":
@@ -552,6 +583,9 @@ def main():
             elif leg == "lap7_256_var":
                 out["legs"][leg] = spmv_leg(P, L, comm, tm, leg, "lap7", 256, True, False, a.steps, fmt_csr_too=True)
                 out["legs"][leg]["is"] = "out-of-cache, non-dictionary SpMV: the general stencil path (SELL-dict streamed values) and the general CSR row-block kernel on the same matrix"
+            elif leg.startswith("rmat_"):
+                out["legs"][leg] = rmat_leg(P, L, comm, tm, leg, int(leg.split("_")[1]))
+                out["legs"][leg]["is"] = "BASELINE config 5's matrix family: irregular (power-law) SpMV through the CSR row-block kernel"
             else:
                 k2, n2 = parse_workload(leg)
                 out["legs"][leg] = spmv_leg(P, L, comm, tm, leg, k2, n2, False, True, max(a.steps, 20))
