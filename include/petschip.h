@@ -171,6 +171,12 @@ int phip_set_setup_threads(int nthreads);
  * 4 / 5: that kernel for every size; 6: spmv_dmasks_kernel, the group-descriptor kernel with the windows of x staged in LDS (a third of
  * the L1 traffic for a 27-point stencil, but measured slower: never chosen by itself).  PHIP_DMASK_KERNEL sets the initial value. */
 int phip_set_dmask_kernel(int kind);
+/* tuning, process-wide: how the CSR row-block and SELL-dict kernels deal their work items (row blocks / slices) to the eight XCDs, each of
+ * which has an L2 of its own: runs of `chunk` consecutive items per XCD (a power of two; 0 = the kernels' defaults, 128 row blocks / 8 slices;
+ * PHIP_XCD_CHUNK sets the initial value), 1 = item i on XCD i mod 8 (round robin, the hardware's order).  Neighbouring items of a banded matrix share lines of x; in runs
+ * they share them inside one L2 instead of fetching them over the fabric once per XCD.  Same bits either way (no reference counterpart:
+ * MatMult_SeqAIJ, aij.c:1313-1320, is one loop on one core). */
+int phip_set_xcd_chunk(int chunk);
 /* the transposed masks of spmv_dmaskg_kernel: waves (of 256 rows) and distinct sets of mask words among them (equal sets are stored
  * once, 1056 bytes each, plus a 4-byte set number per wave); 0 / 0 without the diagonal-mask layout */
 int phip_mat_mask_sets_info(phip_mat A, int64_t *nsets, int64_t *nwaves);

@@ -41,8 +41,9 @@
 #include <unordered_map>
 #include <vector>
 
-#define SPMV_CAP 2046          /* nonzeros per row block; +2 alignment slack = 2048 LDS doubles = 16 KiB */
-#define SPMV_PAIRS 1024        /* (SPMV_CAP + 2) / 2 */
+#define SPMV_ALIGN 32          /* a block's stream starts at a multiple of 32 entries: whole 128-byte lines of col (and of val) per wave-instruction */
+#define SPMV_CAP 2016          /* nonzeros per row block; + (SPMV_ALIGN - 1) entries of alignment slack in front <= 2048 LDS doubles = 16 KiB */
+#define SPMV_PAIRS 1024        /* (SPMV_CAP + SPMV_ALIGN) / 2 */
 #define SPMV_ROWS_MAX 256      /* rows per block */
 #define SELL_H 512             /* rows per SELL slice = 2 rows per lane */
 #define SELL_MAX_OFFS 256
@@ -214,6 +215,46 @@ __device__ __forceinline__ void st_result2(double *p, double a, double b, bool n
   else *reinterpret_cast<double2 *>(p) = make_double2(a, b);
 }
 
+/* Workgroups are dealt to the eight XCDs round robin (workgroup i runs on XCD i mod 8) and every XCD has an L2 of its own, so with
+   work item i = workgroup i the neighbours i - 1, i, i + 1 -- which share lines of x in any banded matrix (7-point 256^3: the row block
+   one grid line up or down IS the next block) -- sit on three XCDs and each of those lines crosses the fabric three times (PMC, round 2:
+   2.07 GB for 1.74 GB of algorithmic bytes).  xcd_chunk_map deals the work items out in runs of 2^lc consecutive items per XCD instead:
+   item = ((chunk * 8 + xcd) << lc) + k for the k-th workgroup of that XCD's chunk.  All XCDs still sweep the same 8 * 2^lc items at a
+   time (one contiguous eighth of the matrix per XCD was slower: DESIGN.md section 3).  Items behind the last full span keep i. */
+__device__ __forceinline__ int xcd_chunk_map(int i, int n, int lc)
+{
+  if (lc <= 0) return i;
+  const int span = 8 << lc;
+  if (i >= (n & ~(span - 1))) return i;
+  const int j = i >> 3;
+  return (((((j >> lc) << 3) + (i & 7)) << lc) + (j & ((1 << lc) - 1)));
+}
+static int g_xcd_chunk_log2 = -1; /* phip_set_xcd_chunk; -1: PHIP_XCD_CHUNK (a power of two, 1 = off) or the kernel's own default */
+/* measured (7-point 256^3, every value perturbed; chunk 1 / 16 / 64 / 128): CSR row blocks 311 / 317 / 303 / 302 us, SELL-dict slices
+   219 / 216 / 221 / 222 us (best 4..16: 216 us) */
+#define XCD_CHUNK_LOG2_CSR 7
+#define XCD_CHUNK_LOG2_SELL 3
+static int xcd_chunk_log2(int kernel_default)
+{
+  static const int env = [] {
+    if (!getenv("PHIP_XCD_CHUNK")) return -1;
+    int c = atoi(getenv("PHIP_XCD_CHUNK")), l = 0;
+    while ((2 << l) <= c && l < 12) l++;
+    return l;
+  }();
+  return g_xcd_chunk_log2 >= 0 ? g_xcd_chunk_log2 : (env >= 0 ? env : kernel_default);
+}
+
+extern "C" int phip_set_xcd_chunk(int chunk)
+{
+  if (chunk == 0) { g_xcd_chunk_log2 = -1; return 0; } /* back to the kernels' defaults */
+  PHIP_REQUIRE(chunk >= 1 && chunk <= 4096 && (chunk & (chunk - 1)) == 0, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_xcd_chunk: a power of two in 1..4096, or 0 for the defaults");
+  int l = 0;
+  while ((1 << l) < chunk) l++;
+  g_xcd_chunk_log2 = l;
+  return 0;
+}
+
 /* sum += prod[j] for j = j0, j0 + STEP, ... below e, in that order; eight LDS reads are requested before the first is added (the plain
    loop waits out one LDS latency per entry, and with rows of very different lengths in a block that wait is what the block's time is) */
 template <int STEP>
@@ -279,12 +320,13 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(int32_t nbl
                                                                      const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx,
                                                                      const int32_t *__restrict__ col, const double *__restrict__ val,
                                                                      const double *__restrict__ x, const double *__restrict__ yin,
-                                                                     double *__restrict__ yout, int add, int cprow, const double *__restrict__ dotv, RedCtl ctl)
+                                                                     double *__restrict__ yout, int add, int cprow, const double *__restrict__ dotv, RedCtl ctl, int xlc)
 {
   __shared__ __attribute__((aligned(16))) double prod[2 * SPMV_PAIRS];
   const int t = threadIdx.x;
   double    dacc = 0.0;
-  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+  for (int bi = blockIdx.x; bi < nblocks; bi += gridDim.x) {
+    const int  b = xcd_chunk_map(bi, nblocks, xlc);
     const int4 rec = blkrec[b]; /* one scalar load instead of the chain blkrow -> rowptr -> (after the barrier) blktpr */
     const int  r0 = rec.x, r1 = rec.x + (rec.y & 0xffffff), tprl = (int)((unsigned)rec.y >> 24);
     const int  base = rec.z, end = rec.w;
@@ -294,19 +336,21 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(int32_t nbl
       /* eight entries a thread requested together (columns, values, then the eight gathers), added in the order of the plain loop */
       double        sum = 0.0;
       constexpr int LU = 8;
-      for (int j0 = base + t; j0 < end; j0 += LU * PHIP_THREADS) {
+      /* the walk starts at a line boundary in front of the row, so that a wave-instruction covers whole 128-byte lines */
+      for (int j0 = (base & ~(SPMV_ALIGN - 1)) + t; j0 < end; j0 += LU * PHIP_THREADS) {
         int    cj[LU];
         double vj[LU], xj[LU];
 #pragma unroll
         for (int u = 0; u < LU; u++) {
-          const int j = j0 + u * PHIP_THREADS;
-          cj[u] = j < end ? col[j] : col[base];
-          vj[u] = j < end ? val[j] : 0.0;
+          const int  j = j0 + u * PHIP_THREADS;
+          const bool in = j >= base && j < end;
+          cj[u] = in ? col[j] : col[base];
+          vj[u] = in ? val[j] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < LU; u++) xj[u] = x[cj[u]];
 #pragma unroll
-        for (int u = 0; u < LU; u++) if (j0 + u * PHIP_THREADS < end) sum += vj[u] * xj[u];
+        for (int u = 0; u < LU; u++) { const int j = j0 + u * PHIP_THREADS; if (j >= base && j < end) sum += vj[u] * xj[u]; }
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
@@ -320,8 +364,13 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(int32_t nbl
         yout[rout] = s;
       }
     } else {
-      /* phase 1: stream products into LDS.  abase is even so val pairs are 16-byte aligned. */
-      const int abase = base & ~1;
+      /* phase 1: stream products into LDS.  abase is a multiple of 32 entries: every wave-instruction of the stream (64 lanes x 16 bytes
+         of val, x 8 bytes of col) then covers whole 128-byte lines.  With abase = base & ~1 nearly every block started inside a line
+         and each of its 28 wave-instructions shared its first and last line with a neighbour; read with non-temporal loads those lines
+         crossed the fabric twice (PMC, 7-point 256^3 with perturbed values: 15.1 M 128-byte read requests for 12.5 M lines of
+         algorithmic bytes).  The up to 31 entries in front of the block belong to the block before: loaded (same line), multiplied,
+         never summed. */
+      const int abase = base & ~(SPMV_ALIGN - 1);
       /* the bounds of the row this thread sums first (row r0 + t / threads per row; clamped: a thread without a row ignores them) */
       const int rfirst = min(r0 + (t >> tprl), r1 - 1);
       const int ps = rowptr[rfirst], pe = rowptr[rfirst + 1];
@@ -378,7 +427,7 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
                                                                  const double *__restrict__ sval, const uint8_t *__restrict__ scode,
                                                                  const int32_t *__restrict__ soffs, int noffs, const int32_t *__restrict__ scl, int ncl,
                                                                  const double *__restrict__ x, const double *__restrict__ yin, double *__restrict__ yout, int add,
-                                                                 const double *__restrict__ dotv, RedCtl ctl, int nty)
+                                                                 const double *__restrict__ dotv, RedCtl ctl, int nty, int xlc)
 {
 #pragma clang fp contract(off) /* multiply and add round separately, as the reference's compiled loop does (no FMA) */
   extern __shared__ __attribute__((aligned(16))) double xs[]; /* STAGE: the x segments */
@@ -388,9 +437,10 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
   offs[t] = (t < noffs) ? soffs[t] : 0;
   __syncthreads();
   double dacc = 0.0;
-  for (int b = blockIdx.x; b < nslices; b += gridDim.x) {
+  for (int bi = blockIdx.x; bi < nslices; bi += gridDim.x) {
+    const int b = xcd_chunk_map(bi, nslices, xlc);
     if (STAGE) {
-      if (b != (int)blockIdx.x) __syncthreads(); /* the previous slice of this workgroup is done with xs[] */
+      if (bi != (int)blockIdx.x) __syncthreads(); /* the previous slice of this workgroup is done with xs[] */
       for (int c = 0; c < ncl; c++) {
         const int g0 = b * SELL_H + scl[3 * c], s0 = scl[3 * c + 1], len = scl[3 * c + 2];
         for (int i = t; i < len; i += PHIP_THREADS) {
@@ -2316,6 +2366,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     const int      dot_cap = (dot_grid_env > 0 && dot_grid_env <= PHIP_RED_RESIDENT) ? dot_grid_env : 1024;
     const unsigned grid = DOT ? (unsigned)(A->sell_nslices < dot_cap ? A->sell_nslices : dot_cap) : (unsigned)A->sell_nslices;
     const bool     nt = A->nt_user >= 0 ? A->nt_user != 0 : 9 * A->sell_padded > PHIP_NT_MATRIX_BYTES;
+    const int      sxlc = (grid % 8 == 0 || !DOT) ? xcd_chunk_log2(XCD_CHUNK_LOG2_SELL) : 0;
     /* results of 64 MiB and more leave with non-temporal stores: they do not push x out of the caches while the product still
        gathers from it (diagonal masks, 7-point 256^3: 97.9 -> 80.2 us, KSPCG 2759 -> 2805 it/s; 27-point 256^3: 227 -> 205 us;
        192^3, 57 MB: no change).  PHIP_SPMV_NT_Y=0|1 overrides. */
@@ -2330,7 +2381,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
 #define SELL_LAUNCH2(NTv, STv, Uv)                                                                                                                        \
   hipLaunchKernelGGL((spmv_sell_kernel<NTv, DOT, STv, Uv>), dim3(grid), dim3(PHIP_THREADS), (STv) ? sizeof(double) * (size_t)A->stage_lds_doubles : 0, st, A->m, \
                      A->n, A->sell_nslices, A->d_sptr, A->d_slen, A->d_sval, A->d_scode, (STv) ? A->d_sldsoff : A->d_soffs, A->sell_noffs, A->d_scl,      \
-                     A->stage_ncl, d_x, d_yin, d_yout, add, d_v, ctl, nty)
+                     A->stage_ncl, d_x, d_yin, d_yout, add, d_v, ctl, nty, sxlc)
     /* slots requested per lane before the gathers start: 8 for long rows (27-point 192^3: 361.9 -> 349.7 us), 4 otherwise (rows of 7
        never fill a batch of 8: 27.1 -> 36.1 us); PHIP_SELL_UNROLL=4|8 overrides */
     static const int unroll_env = getenv("PHIP_SELL_UNROLL") ? atoi(getenv("PHIP_SELL_UNROLL")) : 0;
@@ -2465,12 +2516,13 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
       hipLaunchKernelGGL(hot_gather_kernel, dim3(g), dim3(256), 0, st, A->n, A->d_horder, d_x, A->d_hx);
       cols = A->d_hcol; xs = A->d_hx;
     }
+    const int xlc = (grid % 8 == 0 || !DOT) ? xcd_chunk_log2(XCD_CHUNK_LOG2_CSR) : 0; /* a strided grid keeps a workgroup on its XCD only if 8 divides it */
     if (csr_nt)
       hipLaunchKernelGGL((spmv_rowblock_kernel<DOT, true>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->nblocks, A->d_blkrec, A->d_rowptr, A->d_ridx, cols,
-                         A->d_val, xs, d_yin, d_yout, add, A->use_cprow, d_v, ctl);
+                         A->d_val, xs, d_yin, d_yout, add, A->use_cprow, d_v, ctl, xlc);
     else
       hipLaunchKernelGGL((spmv_rowblock_kernel<DOT, false>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->nblocks, A->d_blkrec, A->d_rowptr, A->d_ridx, cols,
-                         A->d_val, xs, d_yin, d_yout, add, A->use_cprow, d_v, ctl);
+                         A->d_val, xs, d_yin, d_yout, add, A->use_cprow, d_v, ctl, xlc);
   }
   PHIP_CHECK_HIP(hipGetLastError());
   return 0;

@@ -164,9 +164,10 @@ def test_spmv_sell_dict_layout(ctx, orc, golden_dir):
 
 def test_spmv_long_rows_and_edges(ctx, orc):
     rng = np.random.default_rng(5)
-    # rows of 0, 1, 2046, 2047, 5000 and 40000 nonzeros around the block capacity; empty leading/trailing rows
+    # rows of 0, 1, 2015 ... 2017 (the block capacity is 2016 behind up to 31 entries of alignment slack), 2046, 2047, 5000 and 40000
+    # nonzeros; every start alignment of a full block (the 1..31 nonzeros in front); empty leading/trailing rows
     n = 50000
-    lens = [0, 0, 1, 2046, 2047, 3, 0, 5000, 2045, 2, 40000, 0, 17, 0]
+    lens = [0, 0, 1, 2046, 2047, 3, 0, 5000, 2045, 2, 40000, 0, 17, 0, 2016, 2017, 2015, 1, 2016, 31, 2016, 7, 2010, 6, 5, 2016]
     ai = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     aj = np.concatenate([np.sort(rng.choice(n, L, replace=False)) for L in lens]).astype(np.int32)
     aa = rng.standard_normal(len(aj))
