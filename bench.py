@@ -3,6 +3,8 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload box27_256|lap7_128|lap7_<n>|box27_<n>] [--scaling strong|weak]
                     [--legs auto|none|name,name] [--no-cpu-baseline]
+    python bench.py --gpus N ...           starts its N ranks itself (one process per GPU); under torch.distributed.run it takes the ranks given
+    --workload box27_256_var               the same system with a value of its own in every stored entry (no dictionary: SELL-dict streamed / CSR)
 
 A "step" is one KSPCG + PCJACOBI iteration through MATAIJHIP / VECHIP (cg.c:180-275: MatMult, 2 VecTDot, VecNorm, 2 VecAXPY,
 VecAYPX, PCApply), i.e. one pass of the whole hot path.  The K timed steps are ONE KSPSolve capped at K iterations (rtol 0), so
@@ -12,19 +14,22 @@ Default workload, at every N: BASELINE.json configs[2], the north star -- KSPCG+
 scaling: the same global matrix cut into MPIAIJ row blocks (z-slabs), ghost exchange and reductions between the ranks.  It fits one
 GPU, so N = 1 runs it too and value(N) / value(1) is the strong-scaling speed-up the >= 6x target is quoted on.
 
-value    = whole-job ALGORITHMIC bytes of the K iterations / wall time (GB/s): per rank and iteration SpMV 12 nz + 20 m + 4 (+ the
-           off-diagonal block's MultAdd 12 nzB + 28 mB on N > 1) + 136 m of vector kernels (the reference's
-           passes; the library's two fused launches move 80 m).  KSPCG iterations/s ride along.
+value    = whole-job bytes the K iterations REALLY move through HBM / wall time (GB/s): per rank and iteration the SpMV's bytes in its device
+           layout (x and y once each; + the off-diagonal block's MultAdd 12 nzB + 28 mB on N > 1) + 80 m of the two fused vector launches.
+           Never above N x 8 TB/s.  The algorithmic bytes of SURVEY.md 8d (12 nz + 20 m + 4 + 136 m: what the reference's passes move)
+           ride along as algorithmic_bytes_per_iteration, KSPCG iterations/s as cg_iters_per_s.
 roofline = the kernel with the largest share of the timed iteration, priced on the bytes it REALLY moves in its device layout (never
-           more than the algorithmic CSR bytes) over its average launch time: frac <= 1 by construction.  The algorithmic figure
-           (12 nz + 20 m + 4 over the same time) is reported beside it as effective_GBps.  Every other kernel of the iteration and
-           every leg carries an object of the same shape under "kernels" / "legs".
+           more than the algorithmic CSR bytes) over its average launch time: frac <= 1 by construction.  Every other kernel of the
+           iteration and every leg carries an object of the same shape under "kernels" / "legs".
 legs     (N = 1, rank 0): the other single-GPU measurements the metric names --
            lap7_128      BASELINE configs[1]: 7-point 128^3 SpMV (the >= 70 % target) + KSPCG it/s; the working set fits the 256 MiB
                          Infinity Cache, which the leg says
            lap7_256_var  7-point 256^3 with per-entry perturbed values (what a variable-coefficient / FEM assembly gives): no value
                          dictionary applies, the matrix streams 9 B/nz (SELL-dict) from HBM, 1.5 GB per launch, far outside the caches
-                         ("roofline"), and the same matrix through the general CSR row-block kernel ("roofline_csr", 12 B/nz, any matrix)
+                         ("roofline"), and the same matrix through the general CSR row-block kernel ("roofline_csr", 12 B/nz, any matrix);
+                         KSPCG+PCJACOBI iterations/s through both
+           box27_256_var the north-star system (27-point 256^3) the same way: what a MatSetValues-assembled operator gets
+           rmat_22       BASELINE config 5's matrix family (R-MAT) through the CSR row-block kernel
 cpu_baseline = the oracle (C restatement of the reference loops, -O3 -march=native) on the same system: 16 row blocks / threads as
            MATMPIAIJ would run it on the host's CPU share, and one core (MATSEQAIJ); rank 0 at N = 1 only, bounded sample.
 Timing: hipEvents on the library's compute stream.  avg = K launches back to back between two events (best of 3); p10/p50/p90 = the
@@ -48,11 +53,30 @@ REPS = 200
 
 
 def parse_workload(name):
-    kind, _, n = name.partition("_")
-    n = int(n)
-    if kind not in ("lap7", "box27"):
+    """lap7_<n> | box27_<n> [+ _var: every stored entry gets a value of its own] -> (kind, n, perturb)"""
+    parts = name.split("_")
+    if len(parts) not in (2, 3) or parts[0] not in ("lap7", "box27") or not parts[1].isdigit() or (len(parts) == 3 and parts[2] != "var"):
         raise SystemExit("unknown workload %s" % name)
-    return kind, n
+    return parts[0], int(parts[1]), len(parts) == 3
+
+
+def perturb_values(ai, aj, aa, rs):
+    """every stored entry gets a value of its own (what a variable-coefficient / FEM assembly gives: nothing for a value dictionary to
+    find), symmetric and diagonally dominant like the stencil it starts from: a(i,j) and a(j,i) get the same factor from a hash of
+    (min, max) of the GLOBAL indices -- independent of the partition -- off-diagonal entries shrink by up to 1e-3, diagonal entries grow."""
+    m = len(ai) - 1
+    row = np.repeat(np.arange(rs, rs + m, dtype=np.int64), np.diff(ai).astype(np.int64))
+    lo = np.minimum(row, aj).astype(np.uint64)
+    hi = np.maximum(row, aj).astype(np.uint64)
+    diag = row == aj
+    del row
+    k = (lo * np.uint64(0x9E3779B97F4A7C15) + hi * np.uint64(0xC2B2AE3D27D4EB4F))
+    del lo, hi
+    k ^= k >> np.uint64(29)
+    k *= np.uint64(0xBF58476D1CE4E5B9)
+    delta = (k >> np.uint64(40)).astype(np.float64) * (1e-3 / float(1 << 24))
+    del k
+    return aa * np.where(diag, 1.0 + delta, 1.0 - delta)
 
 
 def local_rows(kind, n, size, rank, scaling, perturb=False):
@@ -64,10 +88,8 @@ def local_rows(kind, n, size, rank, scaling, perturb=False):
     rs = sum(N // size + (1 if (N % size) > r else 0) for r in range(rank))
     # = G.laplace3d_7pt(..., dirichlet_rows=False) / G.box3d_27pt(...), built by the C loop of the host library (tests/test_host_cpu.py)
     ai, aj, aa = G.stencil_rows_native(7 if kind == "lap7" else 27, n, n, nzdim, rs, rs + m)
-    if perturb:  # every stored entry gets a value of its own (relative change <= 1e-3): nothing for a value dictionary to find
-        k = np.arange(int(ai[0]), int(ai[0]) + len(aa), dtype=np.uint64)
-        k = (k * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)
-        aa = aa * (1.0 + 1e-3 * (k.astype(np.float64) / float(1 << 24) - 0.5))
+    if perturb:
+        aa = perturb_values(ai, aj, aa, rs)
     return N, m, rs, ai, aj, aa
 
 
@@ -114,6 +136,40 @@ class Timer:
             self.L.phip_event_destroy(self.ctx, e)
         return out
 
+    def cold(self, fn, reps=24):
+        """average us of fn()'s launch when nothing it reads is left in L2 / Infinity Cache: before every bracketed launch a VecDot over two
+        512 MiB vectors reads 1 GiB through the caches (read-only, so the launch does not pay for the sweep's write-backs; outside the event pair)"""
+        from petsc_amd.capi import Context
+        n = 1 << 26
+        if getattr(self, "_sweep", None) is None:
+            dev = Context.__new__(Context)
+            dev.lib, dev.h = self.L, self.ctx
+            self._sweep = (dev, dev.malloc(8 * n), dev.malloc(8 * n))
+            self.L.phip_vec_set(self.ctx, n, self._sweep[1], 1.0)
+            self.L.phip_vec_set(self.ctx, n, self._sweep[2], 0.0)
+        _, sx, sy = self._sweep
+        ev = [(self._ev(), self._ev()) for _ in range(reps)]
+        for e0, e1 in ev:
+            z = C.c_double()
+            rc = self.L.phip_vec_dot(self.ctx, n, sx, sy, C.byref(z))
+            assert rc == 0, self.L.phip_last_error()
+            self.L.phip_event_record(self.ctx, e0)
+            fn()
+            self.L.phip_event_record(self.ctx, e1)
+        out, ms = [], C.c_float()
+        for e0, e1 in ev:
+            rc = self.L.phip_event_elapsed_ms(self.ctx, e0, e1, C.byref(ms))
+            assert rc == 0, self.L.phip_last_error()
+            out.append(ms.value * 1e3)
+            self.L.phip_event_destroy(self.ctx, e0); self.L.phip_event_destroy(self.ctx, e1)
+        return float(np.mean(out[2:])), [round(pct(out[2:], q), 2) for q in (10, 50, 90)]
+
+    def close(self):
+        if getattr(self, "_sweep", None) is not None:
+            dev, sx, sy = self._sweep
+            dev.free(sx); dev.free(sy)
+            self._sweep = None
+
     def kernel(self, fn, reps=REPS, warm=20):
         """-> (avg_us back to back, [p10, p50, p90] us of individually bracketed launches)"""
         for _ in range(warm):
@@ -155,30 +211,55 @@ def layout_of(L, hA, m, n, nz):
     return "spmv_sell_kernel", "SELL-dict, streamed values (8 B value + 1 B diagonal code per stored entry)", 9 * pad_.value + m + 8 * nsl + 8 * n + 8 * m, alg
 
 
+def source_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources the running library was built from: committed counter files carry the same
+    figure (scripts/summarize_profiles.py), so a figure measured on other kernels of the same name is flagged, not passed on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "petsc_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+TRAFFIC_FILE = "profiles/r03_hbm_traffic.json"
+_traffic = None
+
+
 def traffic_for(workload, kernel):
-    """HBM bytes per launch from a committed rocprofv3 --pmc measurement of THIS workload and kernel (profiles/r02_hbm_traffic.json,
-    written by scripts/collect_profiles.sh on the GPU box), or None.  Offline by nature: a process cannot count its own HBM traffic."""
-    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-    try:
-        e = json.load(open(path)).get("%s:%s" % (workload, kernel))
-    except (OSError, ValueError):
-        return None, None
+    """HBM bytes per launch from a committed rocprofv3 --pmc measurement of THIS workload and kernel (profiles/r03_hbm_traffic.json,
+    written by scripts/collect_profiles.sh on the GPU box), or None.  Offline by nature: a process cannot count its own HBM traffic.
+    -> (bytes, source text, stale?) ; stale = the file was measured on other kernel sources than the ones this library was built from."""
+    global _traffic
+    if _traffic is None:
+        try:
+            _traffic = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+            _traffic["_stale"] = _traffic.get("_source_sha16") != source_sha16()
+        except (OSError, ValueError):
+            _traffic = {}
+    e = _traffic.get("%s:%s" % (workload, kernel))
     if not e:
-        return None, None
-    return e.get("bytes_per_launch"), "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE; %s)" % e.get("source", "")
+        return None, None, None
+    return (e.get("bytes_per_launch"), "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE; %s; profiled launch %.1f us)"
+            % (TRAFFIC_FILE, e.get("source", ""), e.get("kernel_stats_avg_us") or float("nan")), bool(_traffic.get("_stale")))
 
 
 def roofline_obj(workload, kernel, layout, real_bytes, alg_bytes, avg_us, pcts, resident_bytes=None, extra=None):
+    """achieved = bytes the kernel REALLY moves in its device layout (x and y once each; never more than the algorithmic CSR bytes
+    12 nz + 20 m + 4 of SURVEY.md 8d) / average launch time, so no figure exceeds the HBM peak.  Where the layout streams fewer bytes than
+    CSR the ratio is reported as algorithmic_over_layout_bytes (no GB/s is quoted on bytes that never moved)."""
     ach = real_bytes / (avg_us * 1e-6) / 1e9
-    traffic, src = traffic_for(workload, kernel)
+    traffic, src, stale = traffic_for(workload, kernel)
     o = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-         "traffic": traffic, "traffic_source": src, "bytes_per_launch": int(real_bytes), "avg_launch_us": round(avg_us, 2), "launch_us_p10_p50_p90": pcts,
+         "traffic": traffic, "traffic_source": src, "traffic_stale": stale, "bytes_per_launch": int(real_bytes), "avg_launch_us": round(avg_us, 2), "launch_us_p10_p50_p90": pcts,
          "launches_timed": REPS, "layout": layout,
-         "algorithmic_bytes_per_launch": int(alg_bytes), "effective_GBps": round(alg_bytes / (avg_us * 1e-6) / 1e9, 1),
-         "effective_pct_of_peak": round(alg_bytes / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBPS * 100, 1),
-         "achieved_is": "bytes the kernel moves in its device layout (x and y once each) / average launch time; effective_GBps prices the same time on the algorithmic CSR bytes 12 nz + 20 m + 4 of SURVEY.md 8d"}
+         "algorithmic_bytes_per_launch": int(alg_bytes), "algorithmic_over_layout_bytes": round(alg_bytes / float(real_bytes), 3),
+         "achieved_is": "bytes the kernel moves in its device layout (x and y once each) / average launch time"}
+    if alg_bytes <= 1.001 * real_bytes:
+        o["streams_the_csr"] = True  # the SURVEY.md 8d figure and the real figure coincide: frac IS the north star's "% of HBM peak on 12 nz + 20 m + 4"
     if resident_bytes is not None and resident_bytes < (240 << 20):
-        o["cache_note"] = "working set %.0f MB fits the 256 MiB Infinity Cache: back-to-back launches are served on-die, achieved is cache bandwidth, not HBM" % (resident_bytes / 1e6)
+        o["cache_note"] = "working set %.0f MB fits the 256 MiB Infinity Cache: back-to-back launches are served on-die, achieved is cache bandwidth, not HBM (cold_launch_us: the same launch behind a 1 GiB read sweep)" % (resident_bytes / 1e6)
     if extra:
         o.update(extra)
     return o
@@ -261,31 +342,27 @@ def rmat_leg(P, L, comm, tm, name, scale):
     return out
 
 
-def spmv_leg(P, L, comm, tm, name, kind, n, perturb, with_cg, steps, fmt_csr_too=False):
-    """single-GPU leg: SpMV roofline of the layout the library picks (and, fmt_csr_too, of the CSR row-block kernel on the same matrix)"""
+def spmv_leg(P, L, comm, tm, name, kind, n, perturb, with_cg, steps, fmt_csr_too=False, cold=False):
+    """single-GPU leg: SpMV roofline of the layout the library picks (and, fmt_csr_too, of the CSR row-block kernel on the same matrix);
+    with_cg: KSPCG+PCJACOBI iterations/s through each of them; cold: the launch also timed behind a cache sweep"""
     t0 = time.time()
     N, m, rs, ai, aj, aa = local_rows(kind, n, 1, 0, "strong", perturb)
     nz = int(ai[-1])
     A = P.Mat.seqaij_with_arrays(comm, m, m, ai, aj, aa)
+    del ai, aj, aa
     setup_s = time.time() - t0
     hA = A.device_mat(0)
     x, y = A.create_vecs()
     x.set_array(np.linspace(-1.0, 1.0, m))
     dx, dy = x.device_ptr(), y.device_ptr()
     out = {"matrix": "3-D %s-point %s %d^3%s" % ("7" if kind == "lap7" else "27", "Laplacian" if kind == "lap7" else "box stencil", n,
-                                                  ", every entry perturbed by <= 1e-3 (no two values alike)" if perturb else ""),
+                                                  ", every stored entry with a value of its own (symmetric, <= 1e-3 relative; no value dictionary applies)" if perturb else ""),
            "rows": m, "nnz": nz, "setup_s": round(setup_s, 2)}
-    kernel, layout, real, alg = layout_of(L, hA, m, m, nz)
-    avg, pcts = tm.kernel(lambda: L.phip_mat_mult(hA, dx, dy))
-    out["roofline"] = roofline_obj(name, kernel, layout, real, alg, avg, pcts, resident_bytes=real)
-    if fmt_csr_too:
-        assert L.phip_mat_set_format(hA, 1) == 0
-        k2, l2, r2, a2 = layout_of(L, hA, m, m, nz)
-        avg2, p2 = tm.kernel(lambda: L.phip_mat_mult(hA, dx, dy))
-        out["roofline_csr"] = roofline_obj(name, k2, l2, r2, a2, avg2, p2, resident_bytes=r2)
-        assert L.phip_mat_set_format(hA, 0) == 0
+    b = None
     if with_cg:
         b = y.duplicate()
+
+    def cg_rate(alg):
         x.set(1.0)
         A.mult(x, b)
         ksp = P.KSP(comm, "cg", "jacobi")
@@ -298,10 +375,32 @@ def spmv_leg(P, L, comm, tm, name, kind, n, perturb, with_cg, steps, fmt_csr_too
         res = ksp.solve(b, x)
         L.phip_device_sync(comm.ctx)
         dt = time.perf_counter() - t1
-        assert res["its"] == steps
-        out["cg_iters_per_s"] = round(steps / dt, 1)
-        out["cg_GBps_algorithmic"] = round((alg + 136 * m) * steps / dt / 1e9, 1)
-        ksp.destroy(); b.destroy()
+        assert res["its"] == steps, res
+        ksp.destroy()
+        x.set_array(np.linspace(-1.0, 1.0, m))
+        return round(steps / dt, 1)
+
+    def one(key, suffix):
+        kernel, layout, real, alg = layout_of(L, hA, m, m, nz)
+        avg, pcts = tm.kernel(lambda: L.phip_mat_mult(hA, dx, dy))
+        extra = None
+        if cold:
+            cavg, cp = tm.cold(lambda: L.phip_mat_mult(hA, dx, dy))
+            extra = {"cold_launch_us": round(cavg, 2), "cold_launch_us_p10_p50_p90": cp, "cold_frac": round(real / (cavg * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "cold_is": "the same launch with matrix, x and y evicted (1 GiB read through the caches before every bracketed launch): every byte comes from HBM"}
+        out[key] = roofline_obj(name, kernel, layout, real, alg, avg, pcts, resident_bytes=real, extra=extra)
+        if with_cg:
+            out["cg_iters_per_s" + suffix] = cg_rate(alg)
+            out["cg_real_GBps" + suffix] = round((real + 80 * m) * out["cg_iters_per_s" + suffix] / 1e9, 1)
+
+    one("roofline", "")
+    if fmt_csr_too:
+        assert L.phip_mat_set_format(hA, 1) == 0
+        one("roofline_csr", "_csr")
+        assert L.phip_mat_set_format(hA, 0) == 0
+    if with_cg:
+        out["cg_real_GBps_is"] = "(bytes the SpMV moves in its layout + 80 m of the two fused vector launches) x iterations/s"
+        b.destroy()
     for o in (x, y, A):
         o.destroy()
     return out
@@ -314,18 +413,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="box27_256")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
-    ap.add_argument("--legs", default="auto", help="auto (N=1: lap7_128,lap7_256_var,rmat_22) | none | comma-separated names (lap7_<n>, box27_<n>, rmat_<scale>)")
+    ap.add_argument("--legs", default="auto", help="auto (N=1: lap7_128,lap7_256_var,box27_256_var,rmat_22) | none | comma-separated names (lap7_<n>, box27_<n>, rmat_<scale>)")
     ap.add_argument("--ksp", default="cg", choices=["cg", "pipecg"], help="developer switch; the judged metric is KSPCG")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # a plain `python bench.py --gpus N`: this process becomes the launcher -- before it touches HIP, RCCL or torch -- of N fresh
+        # ranks, one GPU each (the reference's parallel tests are launched the same way: cmake/TestRunner.cmake:5-18, `${MPIEXEC} -n N exe`)
+        raise SystemExit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (a.gpus, world))
         a.gpus = world
     dist = None
     if world > 1:
@@ -336,7 +437,7 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from petsc_amd import capi, petsc as P
-    kind, n = parse_workload(a.workload)
+    kind, n, perturb = parse_workload(a.workload)
     backend = "self"
     if world > 1:
         # data path: RCCL (one GPU per rank).  PHIP_BENCH_BACKEND=shm stages the ghost exchange through host shared memory instead, so
@@ -406,7 +507,7 @@ def main():
         dsync()
 
     t0 = time.time()
-    N, m, rs, ai, aj, aa = local_rows(kind, n, world, rank, a.scaling)
+    N, m, rs, ai, aj, aa = local_rows(kind, n, world, rank, a.scaling, perturb)
     nz_local = int(ai[-1])
     halo = None
     if world > 1:
@@ -438,7 +539,8 @@ def main():
     hA = A.device_mat(0)
     kernel_name, layout_name, real_bytes, spmv_bytes = layout_of(L, hA, m, m, nzA)
     spmv_add_bytes = (12 * nzB + 28 * mB) if nzB else 0
-    iter_bytes = spmv_bytes + spmv_add_bytes + 136 * m
+    iter_bytes = spmv_bytes + spmv_add_bytes + 136 * m          # algorithmic: SURVEY.md 8d (the reference's passes)
+    iter_real_bytes = real_bytes + spmv_add_bytes + 80 * m      # really moved: the SpMV's layout bytes + the two fused vector launches (40 m each)
 
     run(max(a.warmup, 1))
     barrier()
@@ -504,26 +606,28 @@ def main():
     x.set_array(xsave)
     vk = vec_kernels(L, comm.ctx, tm, m, a.workload if world == 1 else "", incg_vec.get(2), incg_vec.get(3))
 
-    tot = np.array([float(iter_bytes), float(spmv_bytes + spmv_add_bytes), float(dt), float(spmv_ms), float(b2b_us), float(mm_us), float(m), float(nz_local)])
+    tot = np.array([float(iter_bytes), float(spmv_bytes + spmv_add_bytes), float(dt), float(spmv_ms), float(b2b_us), float(mm_us), float(m), float(nz_local),
+                    float(iter_real_bytes), float(real_bytes + spmv_add_bytes)])
     if dist is not None:
         import torch
-        tb = torch.tensor([tot[0], tot[1]], dtype=torch.float64)
+        tb = torch.tensor([tot[0], tot[1], tot[8], tot[9]], dtype=torch.float64)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         tmx = torch.tensor([tot[2], tot[3], tot[4], tot[5], tot[6], tot[7]], dtype=torch.float64)
         dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
         tmn = torch.tensor([tot[6], tot[7]], dtype=torch.float64)
         dist.all_reduce(tmn, op=dist.ReduceOp.MIN)
-        job_iter_bytes, job_spmv_bytes = float(tb[0]), float(tb[1])
+        job_iter_bytes, job_spmv_bytes, job_iter_real, job_spmv_real = float(tb[0]), float(tb[1]), float(tb[2]), float(tb[3])
         dt, spmv_ms_max, b2b_us_max, mm_us_max = float(tmx[0]), float(tmx[1]), float(tmx[2]), float(tmx[3])
         rows_minmax, nnz_minmax = [int(tmn[0]), int(tmx[4])], [int(tmn[1]), int(tmx[5])]
     else:
         job_iter_bytes, job_spmv_bytes, spmv_ms_max, b2b_us_max, mm_us_max = float(iter_bytes), float(spmv_bytes), spmv_ms, b2b_us, mm_us
+        job_iter_real, job_spmv_real = float(iter_real_bytes), float(real_bytes)
         rows_minmax, nnz_minmax = [m, m], [nz_local, nz_local]
 
     out = None
     if rank == 0:
         ms_per_step = dt * 1e3 / a.steps
-        value = job_iter_bytes * a.steps / dt / 1e9
+        value = job_iter_real * a.steps / dt / 1e9
         resident = real_bytes + 8 * m * 6
         spmv_roof = roofline_obj(a.workload if world == 1 else "%s/%d" % (a.workload, world), kernel_name, layout_name, real_bytes, spmv_bytes, b2b_us, b2b_pcts,
                                  resident_bytes=resident)
@@ -541,15 +645,23 @@ def main():
             "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "KSPCG+PCJACOBI step (MatMult + Krylov vector kernels) on the 3-D %s-point %s %d^3%s, MAT%sAIJHIP/VEC%sHIP, int32/f64, %s scaling over MPIAIJ row blocks"
+            "config": {"workload": "KSPCG+PCJACOBI step (MatMult + Krylov vector kernels) on the 3-D %s-point %s %d^3%s%s, MAT%sAIJHIP/VEC%sHIP, int32/f64, %s scaling over MPIAIJ row blocks"
                        % ("7" if kind == "lap7" else "27", "Laplacian" if kind == "lap7" else "box stencil", n, " per GPU" if a.scaling == "weak" else " (global)",
+                          ", every stored entry with a value of its own" if perturb else "",
                           "SEQ" if world == 1 else "MPI", "SEQ" if world == 1 else "MPI", a.scaling),
                        "name": a.workload, "global_rows": N, "rows_per_gpu_min_max": rows_minmax, "nnz_per_gpu_min_max": nnz_minmax,
-                       "partition": "MPIAIJ row blocks (z-slabs)", "value_is": "algorithmic bytes of one CG iteration x K / wall time, all ranks (max over ranks)"},
+                       "partition": "MPIAIJ row blocks (z-slabs)",
+                       "value_is": "bytes one KSPCG iteration REALLY moves through HBM (the SpMV in its device layout, x and y once each, + 80 B/row of the two fused vector launches "
+                                   "+ the off-diagonal block on N > 1) x K / wall time, summed over the ranks (time = max over ranks): never above N x 8 TB/s.  The algorithmic bytes of "
+                                   "SURVEY.md 8d (12 nz + 20 m + 4 + 136 m, what the reference's passes would move) are under algorithmic_bytes_per_iteration"},
             "cg_iters_per_s": round(a.steps / dt, 1),
-            "spmv": {"effective_GBps_back_to_back": round(job_spmv_bytes / (mm_us_max * 1e-6) / 1e9, 1),
-                     "effective_pct_of_8TBps_per_gpu": round(job_spmv_bytes / world / (mm_us_max * 1e-6) / 1e9 / HBM_PEAK_GBPS * 100, 1),
-                     "effective_GBps_in_cg": round(job_spmv_bytes / (spmv_ms_max * 1e-3) / 1e9, 1) if spmv_ms_max else None,
+            "pct_of_hbm_peak": round(value / (HBM_PEAK_GBPS * world) * 100, 1),
+            "real_bytes_per_iteration": int(job_iter_real), "algorithmic_bytes_per_iteration": int(job_iter_bytes),
+            "algorithmic_over_real_bytes": round(job_iter_bytes / job_iter_real, 3),
+            "spmv": {"real_GBps_back_to_back": round(job_spmv_real / (mm_us_max * 1e-6) / 1e9, 1),
+                     "pct_of_8TBps_per_gpu": round(job_spmv_real / world / (mm_us_max * 1e-6) / 1e9 / HBM_PEAK_GBPS * 100, 1),
+                     "real_GBps_in_cg": round(job_spmv_real / (spmv_ms_max * 1e-3) / 1e9, 1) if spmv_ms_max else None,
+                     "real_bytes_all_ranks": int(job_spmv_real),
                      "matmult_us_back_to_back": round(mm_us_max, 2), "matmult_us_p10_p50_p90_rank0": mm_pcts,
                      "diag_block_kernel_us": round(b2b_us_max, 2), "offdiag_block_kernel_us_rank0": round(offd_us, 2) if offd_us is not None else None,
                      "algorithmic_bytes_all_ranks": int(job_spmv_bytes), "launches_timed": REPS,
@@ -574,30 +686,74 @@ def main():
     if rank == 0 and world == 1:
         legs = a.legs
         if legs == "auto":
-            legs = "lap7_128,lap7_256_var,rmat_22"
+            legs = "lap7_128,lap7_256_var,box27_256_var,rmat_22"
         out["legs"] = {}
         for leg in [s for s in legs.split(",") if s and s != "none"]:
             if leg == "lap7_128":
-                out["legs"][leg] = spmv_leg(P, L, comm, tm, leg, "lap7", 128, False, True, max(a.steps, 20), fmt_csr_too=True)
-                out["legs"][leg]["is"] = ("BASELINE configs[1]: SeqAIJ SpMV + CG on the 3-D 7-point Laplacian 128^3 (target: SpMV >= 70 % of HBM peak on the algorithmic bytes); "
-                                          "roofline = the layout the library picks for this matrix, roofline_csr = the general CSR row-block kernel on it (effective_pct_of_peak is the target's figure)")
-            elif leg == "lap7_256_var":
-                out["legs"][leg] = spmv_leg(P, L, comm, tm, leg, "lap7", 256, True, False, a.steps, fmt_csr_too=True)
-                out["legs"][leg]["is"] = "out-of-cache, non-dictionary SpMV: the general stencil path (SELL-dict streamed values) and the general CSR row-block kernel on the same matrix"
+                out["legs"][leg] = spmv_leg(P, L, comm, tm, leg, "lap7", 128, False, True, max(a.steps, 20), fmt_csr_too=True, cold=True)
+                out["legs"][leg]["is"] = ("BASELINE configs[1]: SeqAIJ SpMV + CG on the 3-D 7-point Laplacian 128^3 (target: SpMV >= 70 % of HBM peak on 12 nz + 20 m + 4); "
+                                          "roofline = the layout the library picks for this matrix, roofline_csr = the general CSR row-block kernel on it, which streams exactly those bytes "
+                                          "(its frac is the target's figure; cold_frac the same with nothing left in the caches)")
             elif leg.startswith("rmat_"):
                 out["legs"][leg] = rmat_leg(P, L, comm, tm, leg, int(leg.split("_")[1]))
                 out["legs"][leg]["is"] = "BASELINE config 5's matrix family: irregular (power-law) SpMV through the CSR row-block kernel"
             else:
-                k2, n2 = parse_workload(leg)
-                out["legs"][leg] = spmv_leg(P, L, comm, tm, leg, k2, n2, False, True, max(a.steps, 20))
+                k2, n2, pv = parse_workload(leg)
+                out["legs"][leg] = spmv_leg(P, L, comm, tm, leg, k2, n2, pv, True, max(min(a.steps, 100), 20), fmt_csr_too=pv)
+                if pv:
+                    out["legs"][leg]["is"] = ("out-of-cache, non-dictionary path -- what a MatSetValues-assembled variable-coefficient operator gets (aij.c:430-501, 1313-1320): SpMV + "
+                                              "KSPCG+PCJACOBI through SELL-dict with streamed values (roofline, cg_iters_per_s) and through the general CSR row-block kernel "
+                                              "(roofline_csr, cg_iters_per_s_csr) on the same matrix")
         if keep_host_csr:
             out["cpu_baseline"] = cpu_baseline(ai, aj, aa, m, iter_bytes, spmv_bytes, a.cpu_seconds)
+    tm.close()
     comm.finalize()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` from a plain shell: start N ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    set, rank r on GPU r modulo the visible devices), wait for them under a time limit, forward rank 0's JSON line, return non-zero when
+    any rank failed.  The launcher itself never initialises HIP.  PHIP_BENCH_TIMEOUT (seconds, default 1500)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    limit = float(os.environ.get("PHIP_BENCH_TIMEOUT", "1500"))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=(r == 0)))
+    t0 = time.time()
+    rc = 0
+    out0 = ""
+    try:
+        out0, _ = procs[0].communicate(timeout=limit)
+        for p_ in procs:
+            p_.wait(timeout=max(limit - (time.time() - t0), 10.0))
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("bench: ranks still running after %.0f s, stopping them\n" % limit)
+        rc = 124
+    for r, p_ in enumerate(procs):
+        if p_.poll() is None:
+            p_.kill()  # exactly the processes started above
+            p_.wait()
+        if p_.returncode and not rc:
+            sys.stderr.write("bench: rank %d exited with %s\n" % (r, p_.returncode))
+            rc = p_.returncode if p_.returncode > 0 else 1
+    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    if lines and not rc:
+        print(lines[-1], flush=True)
+    elif not rc:
+        sys.stderr.write("bench: rank 0 printed no result line\n")
+        rc = 1
+    return rc
 
 
 def host_cores():

@@ -15,7 +15,7 @@ from petsc_amd import capi, petsc as P  # noqa: E402
 from petsc_amd.capi import Ticket  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "box27_256"
-kind, n = parse_workload(name)
+kind, n, _ = parse_workload(name)
 comm = P.Comm(device=0, backend="self")
 L = capi.load()
 tm = Timer(L, comm.ctx)

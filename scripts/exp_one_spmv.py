@@ -24,7 +24,7 @@ if name.startswith("rmat_"):
     ai, aj, aa = G.rmat(int(name.split("_")[1]))
     m = len(ai) - 1
 else:
-    kind, n = B.parse_workload(name)
+    kind, n, _ = B.parse_workload(name)
     N, m, rs, ai, aj, aa = B.local_rows(kind, n, 1, 0, "strong", bool(var))
 nz = int(ai[-1])
 A = P.Mat.seqaij_with_arrays(comm, m, m, ai, aj, aa)

@@ -20,7 +20,7 @@ def main():
     L = capi.load()
     tm = B.Timer(L, comm.ctx)
     for name in names:
-        kind, n = B.parse_workload(name)
+        kind, n, _ = B.parse_workload(name)
         N, m, rs, ai, aj, aa = B.local_rows(kind, n, 1, 0, "strong", True)
         nz = int(ai[-1])
         A = P.Mat.seqaij_with_arrays(comm, m, m, ai, aj, aa)

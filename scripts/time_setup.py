@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from petsc_amd import capi  # noqa: E402
 
-kind, n = bench.parse_workload(sys.argv[1] if len(sys.argv) > 1 else "box27_256")
+kind, n, _ = bench.parse_workload(sys.argv[1] if len(sys.argv) > 1 else "box27_256")
 t = time.time()
 N, m, rs, ai, aj, aa = bench.local_rows(kind, n, 1, 0, "strong")
 print("generate %.2f s" % (time.time() - t), flush=True)
