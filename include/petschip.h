@@ -268,7 +268,11 @@ int phip_read_scalars(phip_ctx ctx, const double *d_src, int32_t n, double *h_ds
  * synchronised.  Limits: 1 <= nv <= 16 per call (PHIP_ERR_ARG_OUTOFRANGE beyond; split longer lists), n >= 0.  Same kernel, grid and
  * summation order as phip_vec_reduce_local: the same bits.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU
  * (two streams, two threads) race; calls on one stream, or ordered by events, do not.  The array is left clean by every launch (the
- * arrival counter returns to 0), so a captured launch may be replayed.  h_dy is a host array of nv device pointers, read before return. */
+ * arrival counter returns to 0), so a captured launch may be replayed.  h_dy is a host array of nv device pointers, read before return.
+ * It takes no context, so it cannot launch a context's DEFERRED elementwise operations (see "vector kernels" above: phip_vec_axpy and
+ * its siblings wait in their context; KSPCG's VecAXPY(X,a,P) stays pending past the reducing product by default): when an operand was
+ * last written through a context, call phip_stream(ctx) or phip_sync(ctx) for that context immediately before, or the sums are taken
+ * over the data as it was before the pending operations. */
 int phip_vec_mdot_static(void *stream, int32_t n, const double *d_x, int32_t nv, const double *const *h_dy, double *d_z);
 
 /* ---- by-product reductions --------------------------------------------------------------------------

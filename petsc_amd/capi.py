@@ -68,6 +68,7 @@ SIGNATURES = [
     ("phip_mat_hot_columns_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pD, _pD]),
     ("phip_set_default_lds_hot", C.c_int, [C.c_int]),
     ("phip_set_dmask_kernel", C.c_int, [C.c_int]),
+    ("phip_set_xcd_chunk", C.c_int, [C.c_int]),
     ("phip_set_setup_threads", C.c_int, [C.c_int]),
     ("phip_set_cg_defer_x", C.c_int, [C.c_int]),
     ("phip_mat_mask_sets_info", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -25,6 +25,7 @@
 #define PETSC_ERR_ARG_WRONGSTATE 73
 #define PETSC_ERR_ARG_INCOMP 75
 #define PETSC_ERR_LIB 76
+#define PETSC_ERR_PLIB 77 /* inconsistent data in this library (petscerror.h) */
 #define PETSC_ERR_FILE_UNEXPECTED 79
 #define PETSC_ERR_ARG_NULL 85
 #define PETSC_ERR_ARG_UNKNOWN_TYPE 86
@@ -1209,6 +1210,9 @@ struct HostAIJ {
   PetscErrorCode upload(phip_ctx ctx)
   {
     if (host_stale && !values_dirty && dev && dev_nonzerostate == nonzerostate) return 0; /* the device holds the newer values */
+    /* both copies changed since they last agreed: every host-side writer syncs first (mat_sync_host), so this is a bug in this file, and
+       pulling the device values here would silently drop the host's edits */
+    if (host_stale && values_dirty) SETERRQ(PETSC_ERR_PLIB, "host values were edited while the device copy held newer ones (missing mat_sync_host)");
     { PetscErrorCode ierr = sync_host(); CHKERRQ(ierr); }
     if (dev && dev_nonzerostate == nonzerostate) {
       if (values_dirty) CHKPHIP(phip_mat_update_values(dev, a.data()));
@@ -1549,6 +1553,10 @@ static PetscErrorCode mat_stash_exchange(Mat A)
   std::vector<int32_t> rbuf(rtot + 1);
   CHKPHIP(phip_comm_alltoallv_i32(A->comm->comm, sbuf.data(), scount.data(), rbuf.data(), rcount.data()));
   A->stash.clear(); A->stash_mode = 0;
+  /* the entries land in the host CSR through MatSetValues_MPIAIJHIP directly (not through the public MatSetValues, which syncs): after a
+     device-side MatScale / MatShift / MatDiagonalScale the host values are behind, and a rank that only RECEIVES entries has not synced
+     them itself -- they must catch up first, or the additions go into stale values and the upload would have to choose between the two */
+  if (rtot) { PetscErrorCode serr = mat_sync_host(A); CHKERRQ(serr); }
   for (size_t k = 0; k + 3 < rtot + 1 && k < rtot; k += 4) {
     PetscInt row = rbuf[k], col = rbuf[k + 1]; double val; memcpy(&val, &rbuf[k + 2], sizeof(double));
     PetscErrorCode ierr = MatSetValues_MPIAIJHIP(A, 1, &row, 1, &col, &val, (InsertMode)mode); CHKERRQ(ierr);

@@ -683,10 +683,15 @@ __global__ __launch_bounds__(PHIP_THREADS) void halo_pack_ipc_kernel(int32_t nse
                                                                    unsigned long long *const *__restrict__ peer_flag, const unsigned long long *acks,
                                                                    unsigned long long seq, unsigned int *counter, unsigned int *err)
 {
-  __shared__ int last;
+  __shared__ int last, bad;
   const int      t = threadIdx.x;
-  if (t < to_n && !ipc_wait_ge(&acks[t], seq - 1) && err) __hip_atomic_store(err, 0x1bc00001u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (t == 0) bad = 0;
   __syncthreads();
+  if (t < to_n && !ipc_wait_ge(&acks[t], seq - 1)) { bad = 1; if (err) __hip_atomic_store(err, 0x1bc00001u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+  __syncthreads();
+  /* a neighbour has not acknowledged the previous exchange: its buffer may still be read, so nothing is stored and no flag is raised --
+     the neighbour's own wait gives up in turn and fills its ghost values with NaN; the error word fails the next host-visible call */
+  if (bad) return;
   const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
   for (int64_t k = (int64_t)blockIdx.x * PHIP_THREADS + t; k < nsend; k += stride) {
     const int i = seg[k];
@@ -705,11 +710,17 @@ __global__ __launch_bounds__(PHIP_THREADS) void halo_wait_ipc_kernel(int32_t nre
                                                                    const double *recv, double *__restrict__ lvec, unsigned long long *const *__restrict__ peer_ack,
                                                                    unsigned int *counter, unsigned int *err)
 {
-  __shared__ int last;
+  __shared__ int last, bad;
   const int      t = threadIdx.x;
-  if (t < from_n && !ipc_wait_ge(&flags[t], seq) && err) __hip_atomic_store(err, 0x1bc00002u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (t == 0) bad = 0;
+  __syncthreads();
+  if (t < from_n && !ipc_wait_ge(&flags[t], seq)) { bad = 1; if (err) __hip_atomic_store(err, 0x1bc00002u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * PHIP_THREADS;
+  if (bad) { /* a segment never arrived: the ghost values become NaN (a stale buffer must not pass for this exchange's) and nothing is acknowledged */
+    for (int64_t k = (int64_t)blockIdx.x * PHIP_THREADS + t; k < nrecv; k += stride) lvec[k] = __longlong_as_double(0x7ff8000000000000ll);
+    return;
+  }
   for (int64_t k = (int64_t)blockIdx.x * PHIP_THREADS + t; k < nrecv; k += stride) /* written by another agent: not through this one's caches */
     lvec[k] = __longlong_as_double((long long)ipc_load_sys(reinterpret_cast<const unsigned long long *>(recv) + k));
   __syncthreads();
@@ -737,9 +748,20 @@ static int halo_ipc_setup(phip_halo h)
     for (int p = 0; p < c->size; p++) if (every[(size_t)p]) { h->ipc_why = "a rank has more than 256 neighbours"; return 0; }
   }
   const size_t nsync = (size_t)h->from_n + (size_t)h->to_n + 2;
-  PHIP_CHECK_HIP(hipMalloc((void **)&h->ipc_recv, sizeof(double) * ((size_t)h->nrecv + 2)));
-  PHIP_CHECK_HIP(hipMalloc((void **)&h->ipc_sync, sizeof(unsigned long long) * nsync));
-  PHIP_CHECK_HIP(hipMemset(h->ipc_sync, 0, sizeof(unsigned long long) * nsync));
+  /* another GPU stores into these two while a kernel of this one polls and reads them: fine-grained device memory (coherent between
+     agents inside a kernel; ordinary hipMalloc memory is only guaranteed coherent at kernel boundaries).  If the runtime refuses the
+     flag, the exchange is not used (ipc_why) rather than run on memory that may serve stale lines. */
+  {
+    hipError_t e1 = hipExtMallocWithFlags((void **)&h->ipc_recv, sizeof(double) * ((size_t)h->nrecv + 2), hipDeviceMallocFinegrained);
+    hipError_t e2 = e1 == hipSuccess ? hipExtMallocWithFlags((void **)&h->ipc_sync, sizeof(unsigned long long) * nsync, hipDeviceMallocFinegrained) : e1;
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      (void)hipGetLastError();
+      if (h->ipc_recv) { hipFree(h->ipc_recv); h->ipc_recv = NULL; }
+      h->ipc_sync = NULL;
+    }
+  }
+  const int have_fine = h->ipc_recv && h->ipc_sync;
+  if (have_fine) PHIP_CHECK_HIP(hipMemset(h->ipc_sync, 0, sizeof(unsigned long long) * nsync));
   PHIP_CHECK_HIP(hipDeviceSynchronize()); /* hipMemset of device memory does not wait: the words must be zero before a neighbour can store into them */
   struct Head { hipIpcMemHandle_t recv, sync; int32_t from_n, to_n, ok, pad; char busid[32]; };
   std::vector<unsigned char> rec(sizeof(Head) + sizeof(int32_t) * ((size_t)2 * h->from_n + 1 + (size_t)h->to_n));
@@ -748,7 +770,7 @@ static int halo_ipc_setup(phip_halo h)
   hd.from_n = h->from_n; hd.to_n = h->to_n;
   if (hipDeviceGetPCIBusId(hd.busid, (int)sizeof(hd.busid), ctx->device) != hipSuccess) hd.busid[0] = 0; /* which GPU the buffers live on */
   hd.busid[sizeof(hd.busid) - 1] = 0;
-  hd.ok = hipIpcGetMemHandle(&hd.recv, h->ipc_recv) == hipSuccess && hipIpcGetMemHandle(&hd.sync, h->ipc_sync) == hipSuccess;
+  hd.ok = have_fine && hipIpcGetMemHandle(&hd.recv, h->ipc_recv) == hipSuccess && hipIpcGetMemHandle(&hd.sync, h->ipc_sync) == hipSuccess;
   (void)hipGetLastError();
   memcpy(rec.data(), &hd, sizeof(hd));
   int32_t *tail = reinterpret_cast<int32_t *>(rec.data() + sizeof(Head));
@@ -760,7 +782,7 @@ static int halo_ipc_setup(phip_halo h)
   if (rc) return rc;
   int allok = 1;
   for (int p = 0; p < c->size; p++) { Head q; memcpy(&q, all[(size_t)p].data(), sizeof(q)); allok = allok && q.ok; }
-  if (!allok) { h->ipc_why = "hipIpcGetMemHandle failed on some rank"; return 0; }
+  if (!allok) { h->ipc_why = "fine-grained device memory or its hipIpcGetMemHandle was refused on some rank"; return 0; }
   std::vector<double *>             peer_recv((size_t)h->to_n + 1, NULL);
   std::vector<unsigned long long *> peer_flag((size_t)h->to_n + 1, NULL), peer_ack((size_t)h->from_n + 1, NULL);
   std::vector<void *>               recv_of((size_t)c->size, NULL), sync_of((size_t)c->size, NULL);
@@ -923,13 +945,14 @@ extern "C" int phip_halo_create(phip_comm comm, int32_t to_n, const int32_t *to_
   PHIP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
   PHIP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
   /* PHIP_HALO_IPC (every rank alike): 1 = the peer-write exchange between the processes of one node (backends rccl and shm), an error if
-     it cannot be set up; 0 = never; unset = try it with the rccl backend when all ranks share the node (the host ring is attached) and
-     keep it only if the trial exchanges pass on every rank, else the grouped ncclSend/ncclRecv path as before */
+     it cannot be set up or its trial exchanges fail; unset or 0 = the backend's own exchange (grouped ncclSend/ncclRecv).  Opt-in only:
+     the path has run between processes sharing one GPU, never yet between two GPUs, and three good trial exchanges do not prove that
+     no later exchange reads a stale line -- it stays off until it has been checked on real xGMI (bench.py's matmult_check is the gate). */
   {
     const char *e = getenv("PHIP_HALO_IPC");
     const int   mode = e ? (atoi(e) ? 1 : 0) : -1;
     const bool  can = comm->size > 1 && (comm->backend == BACKEND_RCCL || comm->backend == BACKEND_SHM);
-    const bool  want = can && (mode == 1 || (mode == -1 && comm->backend == BACKEND_RCCL && comm->hr.slots));
+    const bool  want = can && mode == 1;
     if (want) {
       int rc = halo_ipc_setup(h);
       if (rc) return rc;

@@ -70,6 +70,8 @@ int phip_ew_flush(phip_ctx c);
 #define PHIP_FLUSH(c) do { if ((c)->ew_n) { int _frc = phip_ew_flush(c); if (_frc) return _frc; } } while (0)
 
 void phip_set_error(const char *fmt, ...);
+/* reads and clears the context's pinned error word; PHIP_ERR_LIB (with a message) when a kernel left one there (phip_runtime.hip) */
+int phip_check_device_error(phip_ctx c, const char *what);
 
 /* phip_vec.hip: device address of the static partial rows of phip_vec_mdot_static on the current device (looked up once per device) */
 int phip_static_scratch_setup(unsigned long long **ptr);

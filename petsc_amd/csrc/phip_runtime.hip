@@ -22,6 +22,7 @@ void phip_set_error(const char *fmt, ...)
 
 extern "C" const char *phip_last_error(void) { return g_err; }
 
+extern "C" int phip_finalize(phip_ctx c);
 extern "C" int phip_init(int device, phip_ctx *out)
 {
   PHIP_REQUIRE(out, PHIP_ERR_ARG_NULL, "phip_init: null output");
@@ -73,7 +74,7 @@ extern "C" int phip_init(int device, phip_ctx *out)
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
   { /* phip_vec_mdot_static's rows: the symbol look-up happens here, with this device current, not inside a caller's capture */
     const int rc = phip_static_scratch_setup(NULL);
-    if (rc) return rc;
+    if (rc) { phip_finalize(c); return rc; } /* the message stays in phip_last_error; the half-built context does not leak */
   }
   *out = c;
   return 0;
@@ -145,6 +146,25 @@ extern "C" int phip_free(phip_ctx c, void *d_ptr)
   return 0;
 }
 
+/* A kernel that gave up a bounded wait says so in the context's pinned error word and goes on without the data it waited for: a
+   reduction kernel (phip_reduce.h) stores its launch flag and publishes NaN, the peer-write ghost exchange (phip_comm.hip) stores
+   0x1bc0000{1,2} and fills lvec with NaN.  Every host-visible point -- the calls that fetch a reduction result, phip_sync,
+   phip_device_sync, phip_memcpy_d2h, phip_read_scalars -- reads and clears the word and fails with PHIP_ERR_LIB, so a failed wait
+   cannot pass for a good result. */
+int phip_check_device_error(phip_ctx c, const char *what)
+{
+  if (!c || !c->h_err) return 0;
+  const unsigned int e = __atomic_load_n(c->h_err, __ATOMIC_ACQUIRE);
+  if (!e) return 0;
+  __atomic_store_n(c->h_err, 0u, __ATOMIC_RELAXED);
+  if ((e & 0xfffffff0u) == 0x1bc00000u)
+    phip_set_error("%s: the peer-write ghost exchange gave up waiting for a neighbour's %s; the ghost values of that product are NaN", what,
+                   e == 0x1bc00001u ? "acknowledgement of the previous exchange (nothing was sent)" : "flag (its segment never arrived)");
+  else
+    phip_set_error("%s: a reduction kernel (launch flag %u) gave up waiting for the partial result of one of its workgroups and published NaN; the device is overloaded or a workgroup died", what, e);
+  return PHIP_ERR_LIB;
+}
+
 extern "C" int phip_memcpy_h2d(phip_ctx c, void *d_dst, const void *h_src, size_t bytes)
 {
   PHIP_REQUIRE(c, PHIP_ERR_ARG_NULL, "phip_memcpy_h2d: null context");
@@ -162,7 +182,7 @@ extern "C" int phip_memcpy_d2h(phip_ctx c, void *h_dst, const void *d_src, size_
   PHIP_FLUSH(c);
   if (bytes) PHIP_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
-  return 0;
+  return phip_check_device_error(c, "phip_memcpy_d2h");
 }
 
 extern "C" int phip_memcpy_d2d(phip_ctx c, void *d_dst, const void *d_src, size_t bytes)
@@ -180,7 +200,7 @@ extern "C" int phip_sync(phip_ctx c)
   if (c->device < 0) return 0;
   PHIP_FLUSH(c);
   PHIP_CHECK_HIP(hipStreamSynchronize(c->stream));
-  return 0;
+  return phip_check_device_error(c, "phip_sync");
 }
 
 extern "C" int phip_device_sync(phip_ctx c)
@@ -190,7 +210,7 @@ extern "C" int phip_device_sync(phip_ctx c)
   PHIP_FLUSH(c);
   PHIP_CHECK_HIP(hipSetDevice(c->device));
   PHIP_CHECK_HIP(hipDeviceSynchronize());
-  return 0;
+  return phip_check_device_error(c, "phip_device_sync");
 }
 
 extern "C" void *phip_stream(phip_ctx c)
@@ -228,15 +248,7 @@ int phip_wait_ll(phip_ctx c, const unsigned long long *ll, int n, unsigned long 
     const unsigned long long bits = (__atomic_load_n(&ll[2 * i], __ATOMIC_RELAXED) & 0xFFFFFFFFull) | (__atomic_load_n(&ll[2 * i + 1], __ATOMIC_RELAXED) << 32);
     memcpy(&out[i], &bits, 8);
   }
-  if (c->h_err) { /* a reduction kernel that gave up waiting for a workgroup's partial result says so here (phip_reduce.h) */
-    const unsigned int e = __atomic_load_n(c->h_err, __ATOMIC_ACQUIRE);
-    if (e) {
-      __atomic_store_n(c->h_err, 0u, __ATOMIC_RELAXED);
-      phip_set_error("%s: a reduction kernel (launch flag %u) gave up waiting for the partial result of one of its workgroups and published NaN; the device is overloaded or a workgroup died", what, e);
-      return PHIP_ERR_LIB;
-    }
-  }
-  return 0;
+  return phip_check_device_error(c, what);
 }
 
 extern "C" int phip_read_scalars(phip_ctx c, const double *d_src, int32_t n, double *h_dst)
@@ -245,7 +257,7 @@ extern "C" int phip_read_scalars(phip_ctx c, const double *d_src, int32_t n, dou
   PHIP_REQUIRE(n >= 0 && n <= PHIP_MAX_MVEC, PHIP_ERR_ARG_OUTOFRANGE, "phip_read_scalars: n=%d", n);
   PHIP_NEED_DEVICE(c, "phip_read_scalars");
   PHIP_FLUSH(c);
-  if (!n) { PHIP_CHECK_HIP(hipStreamSynchronize(c->stream)); return 0; }
+  if (!n) { PHIP_CHECK_HIP(hipStreamSynchronize(c->stream)); return phip_check_device_error(c, "phip_read_scalars"); }
   const unsigned long long seq = phip_next_seq(&c->seq);
   hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(PHIP_MAX_MVEC), 0, c->stream, d_src, n, c->h_ll_dev, seq);
   PHIP_CHECK_HIP(hipGetLastError());

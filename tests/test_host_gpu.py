@@ -363,6 +363,46 @@ def test_value_updates_stay_on_device(size):
     assert np.abs(got - S @ np.ones(N)).max() <= 1e-12 * np.abs(S @ np.ones(N)).max()
 
 
+@pytest.mark.parametrize("size", [2, 3])
+def test_stash_after_device_side_scale(orc, size):
+    """Off-process MatSetValues after a device-side MatScale (mpiaij.c:619-629 stash, :719-737 drain): the rank that owns the rows only
+    RECEIVES entries; its host values, behind since the scale ran on the device, must catch up before the entries are added -- and the
+    scale must survive the upload that follows."""
+    import scipy.sparse as sp
+    from petsc_amd import generators as G, petsc as P
+    ai, aj, aa = G.convdiff3d_7pt(7, 6, 5)
+    N = len(ai) - 1
+    S = sp.csr_matrix((aa, aj, ai), shape=(N, N)) * 1.75
+    S = S.tolil()
+    rows = [0, 1, 3]
+    for r in rows:
+        S[r, r] += 0.5          # from the last rank
+        S[r, aj[ai[r] + 1]] += 0.25
+    S = S.tocsr()
+    xg = np.linspace(-1.0, 2.0, N)
+    ref = orc.matmult(S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data, xg)
+
+    def body(comm):
+        rs, re = local_slice(comm, N)
+        A = P.Mat.from_global_csr(comm, ai, aj, aa)
+        x = P.Vec.from_array(comm, xg[rs:re], N)
+        y = x.duplicate()
+        A.mult(x, y)
+        A.scale(1.75)                               # on the device: every rank's host CSR is now behind
+        if comm.rank == comm.size - 1:              # rank 0 sets nothing itself
+            for r in rows:
+                A.set_values([r], [r, int(aj[ai[r] + 1])], [0.5, 0.25], P.ADD_VALUES)
+        A.assemble()
+        A.mult(x, y)
+        out = y.array()
+        for o in (x, y, A):
+            o.destroy()
+        return out
+
+    got = gather(run_ranks(size, body))
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
 def test_ranks_without_rows(orc):
     """More ranks than rows (PetscSplitOwnership gives some ranks nothing, psplit.c:88), a diagonal matrix (no ghost entries anywhere)
     and a matrix whose ranks all talk to all others: products, reductions and a solve still agree with the oracle."""
