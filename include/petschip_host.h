@@ -81,6 +81,8 @@ PetscErrorCode PetscCommRankSize(PetscComm comm, int *rank, int *size); /* MPI_C
 PetscErrorCode PetscCommGetContext(PetscComm comm, phip_ctx *ctx);
 PetscErrorCode PetscCommGetHipComm(PetscComm comm, phip_comm *hipcomm); /* the libpetschip communicator behind it (phip_comm_rank_size, ...) */
 const char    *PetscHipLastError(void);
+/* for callers layered on this library (harness/ksp_restated.cpp): store the text PetscHipLastError returns; returns code */
+PetscErrorCode PetscHipSetError(PetscErrorCode code, const char *msg);
 /* PetscSplitOwnership, src/sys/utils/psplit.c:75-97 */
 PetscErrorCode PetscSplitOwnership(PetscComm comm, PetscInt *n, PetscInt *N);
 
@@ -214,28 +216,9 @@ PetscErrorCode PCApplySymmetricLeft(PC pc, Vec x, Vec y);
 PetscErrorCode PCApplySymmetricRight(PC pc, Vec x, Vec y);
 PetscErrorCode PCJacobiSetType(PC pc, PCJacobiType type);
 PetscErrorCode PCJacobiSetUseAbs(PC pc, PetscBool flg);
+PetscErrorCode PCGetType(PC pc, const char **type); /* NULL before PCSetType */
 PetscErrorCode PCDestroy(PC *pc);
 
-/* ---- KSP (include/petscksp.h) ---- */
-PetscErrorCode KSPCreate(PetscComm comm, KSP *ksp);
-PetscErrorCode KSPSetType(KSP ksp, const char *type);
-PetscErrorCode KSPSetOperators(KSP ksp, Mat Amat, Mat Pmat);
-PetscErrorCode KSPGetPC(KSP ksp, PC *pc);
-PetscErrorCode KSPSetTolerances(KSP ksp, PetscReal rtol, PetscReal abstol, PetscReal dtol, PetscInt maxits);
-PetscErrorCode KSPSetInitialGuessNonzero(KSP ksp, PetscBool flg);
-PetscErrorCode KSPSetNormType(KSP ksp, KSPNormType normtype);
-PetscErrorCode KSPGMRESSetRestart(KSP ksp, PetscInt restart);
-PetscErrorCode KSPGMRESSetCGSRefinementType(KSP ksp, KSPGMRESCGSRefinementType type);
-PetscErrorCode KSPGMRESSetHapTol(KSP ksp, PetscReal tol);
-PetscErrorCode KSPCGSetSingleReduction(KSP ksp, PetscBool flg); /* -ksp_cg_single_reduction, cg.c:226-243,262-268 */
-PetscErrorCode KSPSetResidualHistory(KSP ksp, PetscReal a[], PetscInt na, PetscBool reset);
-PetscErrorCode KSPGetResidualHistory(KSP ksp, PetscReal **a, PetscInt *na);
-PetscErrorCode KSPSetUp(KSP ksp);
-PetscErrorCode KSPSolve(KSP ksp, Vec b, Vec x);
-PetscErrorCode KSPGetIterationNumber(KSP ksp, PetscInt *its);
-PetscErrorCode KSPGetConvergedReason(KSP ksp, KSPConvergedReason *reason);
-PetscErrorCode KSPGetResidualNorm(KSP ksp, PetscReal *rnorm);
-PetscErrorCode KSPDestroy(KSP *ksp);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 KERNEL_SRCS = ["phip_runtime.hip", "phip_spmv.hip", "phip_vec.hip", "phip_comm.hip"]
 HOST_SRCS = ["host/petsc_host.cpp"]
+# test and benchmark harness (NOT product): the reference's unmodified KSP drivers restated on the public entry points of the host library
+HARNESS_SRC = os.path.join(os.path.dirname(HERE), "harness", "ksp_restated.cpp")
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
           "-I/opt/rocm/include", "-I" + os.path.join(os.path.dirname(HERE), "include")]
 
@@ -45,6 +47,15 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
         outs.append(hout)
+        if os.path.exists(HARNESS_SRC):
+            xout = os.path.join(LIBDIR, "libpetschip_harness.so")
+            xdeps = [HARNESS_SRC, os.path.join(os.path.dirname(HARNESS_SRC), "ksp_restated.h")]
+            if force or _stale(xout, xdeps) or os.path.getmtime(hout) > os.path.getmtime(xout):
+                cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", HARNESS_SRC, "-o", xout, "-L" + LIBDIR, "-lpetschip_host", "-Wl,-rpath,$ORIGIN"]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+            outs.append(xout)
     return outs
 
 

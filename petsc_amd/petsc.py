@@ -16,6 +16,9 @@ from . import capi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libpetschip_host.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "petschip_host.h")
+# the restated KSP drivers (test and benchmark harness, not product): loaded only when a KSP* function is first asked for
+HARNESS_LIB_PATH = os.path.join(_HERE, "lib", "libpetschip_harness.so")
+HARNESS_HEADER = os.path.join(os.path.dirname(_HERE), "harness", "ksp_restated.h")
 
 INSERT_VALUES, ADD_VALUES = 1, 2
 MAT_FINAL_ASSEMBLY, MAT_FLUSH_ASSEMBLY = 0, 1
@@ -55,7 +58,8 @@ def _ctype(decl):
     return _SCALAR[base]
 
 
-def parse_header(path=HEADER):
+def parse_header(path=None):
+    path = path or HEADER
     txt = open(path).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     sigs = {}
@@ -87,18 +91,44 @@ class PetscError(RuntimeError):
 _lib = None
 
 
+def _typed(L, header):
+    for name, (res, args) in parse_header(header).items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+class _Libs:
+    """libpetschip_host.so (the product's PETSc-API mirror) and, behind it, libpetschip_harness.so: an entry point the first does not
+    export (the KSP* drivers) is looked up in the second, which is loaded at that moment -- product-only users never load the harness."""
+
+    def __init__(self, host):
+        self._host, self._harness = host, None
+
+    def harness(self):
+        if self._harness is None:
+            if not os.path.exists(HARNESS_LIB_PATH):
+                raise ImportError("libpetschip_harness.so not found at %s -- build it with `python -m petsc_amd.build`" % HARNESS_LIB_PATH)
+            self._harness = _typed(C.CDLL(HARNESS_LIB_PATH, mode=C.RTLD_GLOBAL), HARNESS_HEADER)
+        return self._harness
+
+    def __getattr__(self, name):
+        try:
+            fn = getattr(self._host, name)
+        except AttributeError:
+            fn = getattr(self.harness(), name)
+        setattr(self, name, fn)
+        return fn
+
+
 def lib():
     global _lib
     if _lib is None:
         capi.load()  # libpetschip.so first (RTLD_GLOBAL), fails loudly if missing
         if not os.path.exists(HOST_LIB_PATH):
             raise ImportError("libpetschip_host.so not found at %s -- build it with `python -m petsc_amd.build`" % HOST_LIB_PATH)
-        L = C.CDLL(HOST_LIB_PATH, mode=C.RTLD_GLOBAL)
-        for name, (res, args) in parse_header().items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = _Libs(_typed(C.CDLL(HOST_LIB_PATH, mode=C.RTLD_GLOBAL), HEADER))
     return _lib
 
 
