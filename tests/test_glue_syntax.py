@@ -62,3 +62,53 @@ def test_every_phip_call_of_the_glue_is_declared():
     declared = set(re.findall(r"\b(phip_[a-z0-9_]+)\s*\(", hdr))
     used = set(re.findall(r"\b(phip_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", open(GLUE).read(), flags=re.S)))
     assert used and used <= declared, used - declared
+
+
+def _petsc_extern_symbols():
+    """names declared PETSC_EXTERN (functions and data) in the reference's public / private headers and the AIJ / Vec implementation
+    headers and sources the constructors chain to; MPIUNI's Petsc_MPI_* come from its mpi.h"""
+    names = set()
+    pats = [os.path.join(REF, "include"), os.path.join(REF, "src", "mat", "impls", "aij"), os.path.join(REF, "src", "vec", "vec", "impls"),
+            os.path.join(REF, "src", "sys", "objects"), os.path.join(REF, "src", "sys", "logging")]
+    for top in pats:
+        for root, _, files in os.walk(top):
+            for f in files:
+                if not f.endswith((".h", ".c")):
+                    continue
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                for m in re.finditer(r"PETSC_(?:EXTERN|VISIBILITY_PUBLIC)\s+([^;{]*?)[;{]", txt, flags=re.S):
+                    decl = m.group(1)
+                    pm = re.search(r"\(\s*\*\s*([A-Za-z_][A-Za-z0-9_]*)\s*\)", decl)   # a function pointer: (*PetscTrMalloc)(...)
+                    fm = re.search(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", decl)
+                    if pm:
+                        names.add(pm.group(1))
+                    elif fm:
+                        names.add(fm.group(1))
+                    else:
+                        names.update(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\b", decl)[-1:])
+                if f == "mpi.h":
+                    names.update(re.findall(r"\b(Petsc_MPI_[A-Za-z_]+|MPIUNI_[A-Za-z_]+)\b", txt))
+    return names
+
+
+def test_glue_object_links_only_against_the_two_boundaries(tmp_path):
+    """Compiled to an object (same headers and stub as the parse test), the glue's undefined symbols are exactly: phip_* entry points
+    declared in include/petschip.h, symbols the reference declares PETSC_EXTERN (what an out-of-tree library can link), and libc/libm.
+    Anything else -- a hidden PETSc routine, a helper of the stand-alone mirror -- would fail at dlopen time inside a real PETSc."""
+    obj = str(tmp_path / "glue.o")
+    cmd = ["gcc", "-c", "-std=gnu99", "-O1", "-fPIC", "-I" + os.path.join(ROOT, "tests", "native", "petscconf_stub"), "-I" + os.path.join(REF, "include"),
+           "-I" + os.path.join(REF, "include", "petsc", "mpiuni"), "-I" + REF, "-I" + os.path.join(ROOT, "include"), GLUE, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    und = subprocess.run(["nm", "-u", obj], capture_output=True, text=True, check=True).stdout.split()
+    und = {u for u in und if u not in ("U", "w")}
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "petschip.h")).read(), flags=re.S)
+    phip = set(re.findall(r"\b(phip_[a-z0-9_]+)\s*\(", hdr))
+    libc = {"sqrt", "memcpy", "memset", "strcmp", "strlen", "__stack_chk_fail", "_GLOBAL_OFFSET_TABLE_", "fabs", "snprintf", "getenv", "atoi"}
+    petsc = _petsc_extern_symbols()
+    stray = sorted(u for u in und if u not in phip and u not in libc and u not in petsc)
+    assert not stray, stray
+    assert any(u.startswith("phip_") for u in und) and "MatCreate_SeqAIJ" in und and "VecCreate_MPI" in und
+    defined = subprocess.run(["nm", "--defined-only", "-g", obj], capture_output=True, text=True, check=True).stdout
+    for name in ("MatCreate_SeqAIJHIP", "MatCreate_MPIAIJHIP", "VecCreate_SeqHIP", "VecCreate_MPIHIP", "VecCreate_HIP", "PetscDLLibraryRegister_petschip"):
+        assert re.search(r"\bT %s\b" % name, defined), name
