@@ -843,13 +843,20 @@ typedef uint32_t phip_u32x16 __attribute__((ext_vector_type(16)));
 #define DMG_WORDS (DMASK_MAX_PAIRS + 1) /* mask entries of a wave: one per pair and an empty one */
 
 /* s[i] += v * w[i + OFF] for the rows i whose lanes the words select.  The four products are formed in all lanes; each sum is then taken
-   with the word as the execution mask, set by the scalar unit -- no test, no select, no branch: two vector instructions a row.  The
-   wave is fully active here (uniform control flow, workgroups of 256), so the mask is restored to all ones. */
+   with the word as the execution mask, set by the scalar unit -- no test, no select, no branch: two vector instructions a row.
+   EXEC is written behind the compiler's back, so the block keeps it whole: the mask it finds is saved in a scalar pair first and put
+   back last (not "all ones": today every caller is wave-uniform code of a fully populated 256-thread workgroup, but an edit that puts
+   a call under divergence must not switch lanes on that the compiler believes off), every write of EXEC sits inside this one asm
+   statement (the compiler schedules nothing into it), and the mask words are ANDed with nothing -- a lane outside the saved mask may
+   add into its own dead copy of s[], which no live lane reads.  tests/test_kernels_gpu.py::test_mask_kernels_partial_last_wave runs the
+   kernels on row counts that leave the last wave and the last workgroup partly without rows. */
 template <int OFF>
 __device__ __forceinline__ void dmg_step(double (&s)[4], const double (&w)[DM4_WIN], double v, const DmWords &mw)
 {
-  double t0, t1, t2, t3;
-  asm volatile("v_mul_f64 %[t0], %[v], %[w0]\n\t"
+  double             t0, t1, t2, t3;
+  unsigned long long saved;
+  asm volatile("s_mov_b64 %[sv], exec\n\t"
+               "v_mul_f64 %[t0], %[v], %[w0]\n\t"
                "v_mul_f64 %[t1], %[v], %[w1]\n\t"
                "v_mul_f64 %[t2], %[v], %[w2]\n\t"
                "v_mul_f64 %[t3], %[v], %[w3]\n\t"
@@ -861,8 +868,9 @@ __device__ __forceinline__ void dmg_step(double (&s)[4], const double (&w)[DM4_W
                "v_add_f64 %[s2], %[s2], %[t2]\n\t"
                "s_mov_b64 exec, %[m3]\n\t"
                "v_add_f64 %[s3], %[s3], %[t3]\n\t"
-               "s_mov_b64 exec, -1"
-               : [s0] "+v"(s[0]), [s1] "+v"(s[1]), [s2] "+v"(s[2]), [s3] "+v"(s[3]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+               "s_mov_b64 exec, %[sv]"
+               : [s0] "+v"(s[0]), [s1] "+v"(s[1]), [s2] "+v"(s[2]), [s3] "+v"(s[3]), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+                 [sv] "=&s"(saved)
                : [v] "s"(v), [w0] "v"(w[OFF]), [w1] "v"(w[OFF + 1]), [w2] "v"(w[OFF + 2]), [w3] "v"(w[OFF + 3]), [m0] "s"(mw.w[0]), [m1] "s"(mw.w[1]),
                  [m2] "s"(mw.w[2]), [m3] "s"(mw.w[3]));
 }

@@ -873,6 +873,47 @@ def test_full_size_config3(orc):
     assert np.abs(res["x"] - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
 
 
+def test_full_size_config3_to_tolerance():
+    """BASELINE config 3 at full size, solved TO TOLERANCE ("a to-tolerance run (rtol 1e-8) for iteration-count parity"):
+    27-point 256^3, b = A 1, KSPCG + PCJACOBI, KSPConvergedDefault (iterativ.c:744-817) with rtol 1e-8 and the defaults of
+    itcreate.c:706-714 otherwise.  The oracle runs the same system as MPIAIJ would on 16 row blocks, one thread each (its -O3 build; the
+    result does not depend on the number of threads, tests/test_oracle.py).  The north star's bar: same reason, iteration count within
+    1, residual norms within 1e-10 (relative to the initial one) at every iteration both solves reach, and the same solution."""
+    from oracle.oracle import Oracle
+    from petsc_amd import generators as G, petsc as P
+    nn = 256
+    n = nn ** 3
+    ai, aj, aa = G.stencil_rows_native(27, nn, nn, nn, 0, n)
+    op = Oracle(fast=True).operator(ai, aj, aa, 16, 16)
+    b = op.mult(np.ones(n))
+    ref = op.solve(b, "cg", "jacobi", rtol=1e-8)
+
+    def body(comm):
+        A = P.Mat.seqaij_with_arrays(comm, n, n, ai, aj, aa)
+        x, y = A.create_vecs()
+        x.set(1.0)
+        A.mult(x, y)
+        np.testing.assert_array_equal(y.array(), b)   # integer-valued entries, sums of at most 27 of them: exact in every order
+        ksp = P.KSP(comm, "cg", "jacobi")
+        ksp.set_operators(A)
+        ksp.set_tolerances(rtol=1e-8)
+        ksp.set_residual_history()
+        res = ksp.solve(y, x)
+        res["x"] = x.array()
+        for o in (ksp, x, y, A):
+            o.destroy()
+        return res
+
+    res = run_ranks(1, body)[0]
+    assert res["reason"] == ref["reason"] == 2, (res["reason"], ref["reason"])        # KSP_CONVERGED_RTOL
+    assert abs(res["its"] - ref["its"]) <= 1 and res["its"] > 100, (res["its"], ref["its"])
+    rn0 = ref["history"][0]
+    k = min(len(res["history"]), len(ref["history"]))
+    assert k >= min(res["its"], ref["its"]) and np.abs(res["history"][:k] - ref["history"][:k]).max() <= 1e-10 * rn0
+    assert res["history"][k - 1] <= 1.0001e-8 * rn0 or res["history"][-1] <= 1e-8 * rn0
+    assert np.abs(res["x"] - 1.0).max() <= 1e-5 and np.abs(res["x"] - ref["x"]).max() <= 1e-9
+
+
 def test_full_size_config1(orc):
     """BASELINE config 1 at full size: src/ksp/ksp/examples/tutorials/ex2.c with -m 1000 -n 1000 (2-D 5-point Laplacian, b = A 1,
     KSPCG + PCJACOBI to rtol 1e-2 / ((m+1)(n+1))) against the oracle: iteration count within 1, same reason, and -- when the counts agree --

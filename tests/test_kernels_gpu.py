@@ -755,6 +755,53 @@ def test_norm_inf_nan(ctx):
     ctx.free(dx)
 
 
+@pytest.mark.parametrize("ny,nx", [(5, 13), (1, 257), (31, 33), (41, 25), (427, 3), (1, 1)])
+def test_mask_kernels_partial_last_wave(ctx, orc, ny, nx):
+    """Row counts that leave the last wave (256 rows) and the last workgroup (1024 rows) of the mask kernels partly or almost wholly
+    without rows: 65, 257, 1023, 1025, 1281, 1.  spmv_dmaskg_kernel writes the execution mask from scalar registers (dmg_step); lanes
+    without rows must neither store nor feed the fused dot.  Both mask kernels, product / MultAdd / product with fused dot, bit for bit
+    against the oracle; the entries of y behind row m (a guard band) stay untouched."""
+    import ctypes as C
+    from petsc_amd import generators as G
+    from petsc_amd.capi import Ticket
+    L = ctx.lib
+    ai, aj, aa = G.laplace2d_5pt(ny, nx)
+    m = ny * nx
+    assert len(ai) - 1 == m
+    A = ctx.mat_create(m, m, ai, aj, aa)
+    du = C.c_int()
+    ctx.check(L.phip_mat_diag_mask_info(A, None, C.byref(du), None))
+    assert du.value == 1 or m < 64   # a matrix of a few rows may stay in the CSR layout: the results are checked all the same
+    x, y0 = G.random_vector(m), np.random.default_rng(m).standard_normal(m)
+    guard = 2048
+    dx, dy0 = ctx.to_device(x), ctx.to_device(y0)
+    ref, refadd = orc.matmult(ai, aj, aa, x), orc.matmultadd(ai, aj, aa, x, y0)
+    for kind in (4, 5):
+        ctx.check(L.phip_set_dmask_kernel(kind))
+        try:
+            dy = ctx.to_device(np.full(m + guard, 7.0))
+            ctx.check(L.phip_mat_mult(A, dx, dy))
+            got = ctx.to_host(dy, m + guard)
+            np.testing.assert_array_equal(got[:m], ref)
+            np.testing.assert_array_equal(got[m:], np.full(guard, 7.0))
+            ctx.check(L.phip_mat_multadd(A, dx, dy0, dy))
+            got = ctx.to_host(dy, m + guard)
+            np.testing.assert_array_equal(got[:m], refadd)
+            np.testing.assert_array_equal(got[m:], np.full(guard, 7.0))
+            t, val = Ticket(), np.zeros(8)
+            ctx.check(L.phip_mat_mult_dot(A, dx, dy, dx, 1, C.byref(t)))
+            ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t), val.ctypes.data_as(C.POINTER(C.c_double))))
+            got = ctx.to_host(dy, m + guard)
+            np.testing.assert_array_equal(got[:m], ref)
+            np.testing.assert_array_equal(got[m:], np.full(guard, 7.0))
+            assert abs(val[0] - x @ ref) <= 1e-13 * np.abs(x * ref).sum() + 1e-300
+            ctx.free(dy)
+        finally:
+            ctx.check(L.phip_set_dmask_kernel(0))
+    ctx.free(dx); ctx.free(dy0)
+    ctx.check(L.phip_mat_destroy(A))
+
+
 def test_mask_kernels_repeated_diagonals(ctx, orc):
     """Diagonals that carry several values each (a coefficient with period 3 along the rows): the pair table then holds several pairs on
     one diagonal, which the group descriptors must place in groups of their own (a place of the window holds one pair).  All mask
