@@ -202,6 +202,20 @@ int phip_set_default_hot_columns(int mode);
 int phip_mat_set_hot_columns(phip_mat A, int on);
 int phip_mat_hot_columns_info(phip_mat A, int *built, int *in_use, double *share_before, double *share_after);
 
+/* Cold-column routing of the CSR row-block layout, for irregular matrices whose x is far larger than L2.  A gather that misses L2 fills a
+ * 128-byte line for 8 useful bytes, whatever the load's cache policy.  The library keeps the H most used columns as x' = x[order] (2 MiB:
+ * they stay in every XCD's L2) and delivers the entries of all other columns to their nonzeros ahead of the product, in CSR order, by two
+ * passes that move whole lines (a scatter by column chunk into bins, a permutation of each 64 KiB bin through LDS); the row-block kernel
+ * then reads them as a stream.  Column indices are renumbered, nonzeros and values stay where they are, every row adds the same products
+ * in the same order: same bits as without (no reference counterpart: MatMult_SeqAIJ, aij.c:1313-1320, gathers through the host's
+ * caches).  Built at phip_mat_create when 8 n >= 24 MiB and the cold columns carry >= 5 % of the nonzeros (mode 1, the default;
+ * PHIP_ROUTE or phip_set_default_route: 0 never, 2 whenever there are cold nonzeros); phip_set_route_hot_columns / PHIP_ROUTE_HOT: H
+ * (default 262144); phip_mat_set_route switches a built routing off and on.  It takes precedence over the hot-column order above. */
+int phip_set_default_route(int mode);
+int phip_set_route_hot_columns(int32_t ncols);
+int phip_mat_set_route(phip_mat A, int on);
+int phip_mat_route_info(phip_mat A, int *built, int *in_use, int32_t *hot_columns, int64_t *cold_nonzeros, int32_t *bins);
+
 /* Hot columns resident in LDS, for the same kind of matrix (CSR row-block layout, columns used very unevenly): the K most used
  * columns (K = what 127 KiB of LDS hold, about 16 000) are copied from x into LDS by every workgroup of a persistent kernel (one
  * 1024-thread workgroup per CU) and gathered from there; a WAVE owns a block of rows (<= 254 nonzeros, <= 64 rows), sums each row with

@@ -69,6 +69,10 @@ SIGNATURES = [
     ("phip_set_default_lds_hot", C.c_int, [C.c_int]),
     ("phip_set_dmask_kernel", C.c_int, [C.c_int]),
     ("phip_set_xcd_chunk", C.c_int, [C.c_int]),
+    ("phip_set_default_route", C.c_int, [C.c_int]),
+    ("phip_set_route_hot_columns", C.c_int, [C.c_int32]),
+    ("phip_mat_set_route", C.c_int, [C.c_void_p, C.c_int]),
+    ("phip_mat_route_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     ("phip_set_setup_threads", C.c_int, [C.c_int]),
     ("phip_set_cg_defer_x", C.c_int, [C.c_int]),
     ("phip_mat_mask_sets_info", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -44,7 +44,12 @@
 #define SPMV_ALIGN 32          /* a block's stream starts at a multiple of 32 entries: whole 128-byte lines of col (and of val) per wave-instruction */
 #define SPMV_CAP 2016          /* nonzeros per row block; + (SPMV_ALIGN - 1) entries of alignment slack in front <= 2048 LDS doubles = 16 KiB */
 #define SPMV_PAIRS 1024        /* (SPMV_CAP + SPMV_ALIGN) / 2 */
+#ifndef SPMV_ROWS_MAX
 #define SPMV_ROWS_MAX 256      /* rows per block */
+#endif
+#ifndef SPMV_WAVES_ATTR
+#define SPMV_WAVES_ATTR
+#endif
 #define SELL_H 512             /* rows per SELL slice = 2 rows per lane */
 #define SELL_MAX_OFFS 256
 #define SELL_MAX_PAD 1.15
@@ -172,6 +177,18 @@ struct phip_mat_s {
   int32_t  nwb;
   double  *d_wavepart;  /* fused dot: one partial per wave of the grid */
   int      nt_user;  /* phip_mat_set_nontemporal: -1 by size (default), 0 cached loads, 1 non-temporal loads of the matrix stream */
+  /* cold-column routing (setup_route): the x entries of rarely used columns are delivered to the nonzeros in CSR order, as a stream */
+  int       rt_built, rt_on;
+  int32_t   rt_H, rt_Hpad;   /* hot columns (gathered from x' = x[rorder]); Hpad = H rounded up to a line */
+  int64_t   rt_ncold;        /* nonzeros in cold columns */
+  int32_t   rt_nbins;        /* bins of ROUTE_BIN consecutive cold nonzeros (CSR order) */
+  int       rt_lc;           /* log2 of the workgroups that share a column chunk of the scatter list (XCD map) */
+  int32_t  *d_rcol;          /* [nnz + pad] hot rank of the column, or Hpad + number of the cold nonzero in CSR order */
+  int32_t  *d_rorder;        /* [H] column of each hot rank */
+  int2     *d_rlist;         /* [ncold] {column, place in rtmp}, sorted by (column chunk, bin, column) */
+  uint16_t *d_rperm;         /* [nbins * ROUTE_BIN] cold nonzero q finds its entry at rtmp[bin * ROUTE_BIN + rperm[q]] */
+  double   *d_rtmp;          /* [nbins * ROUTE_BIN] the routed entries, bin-major, inside a bin in list order */
+  double   *d_xe;            /* [Hpad + nbins * ROUTE_BIN + pad] what the row-block kernel gathers from: x' then the routed entries in CSR order */
 };
 
 /* Matrix entries are read once per launch.  When the matrix is much larger than the 256 MiB Infinity Cache, non-temporal loads keep
@@ -316,7 +333,7 @@ __device__ __forceinline__ void spmv_reduce_rows(const double *prod, const int32
 /* DOT: also accumulate sum_i dotv[i] * (A x)_i (the increment, for MultAdd) and leave it where ctl says; the grid then strides over
    the row blocks with a capped number of workgroups (launch_spmv_t).  Without DOT the grid is one workgroup per row block. */
 template <bool DOT, bool NT>
-__global__ __launch_bounds__(PHIP_THREADS) void spmv_rowblock_kernel(int32_t nblocks, const int4 *__restrict__ blkrec,
+__global__ __launch_bounds__(PHIP_THREADS) SPMV_WAVES_ATTR void spmv_rowblock_kernel(int32_t nblocks, const int4 *__restrict__ blkrec,
                                                                      const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx,
                                                                      const int32_t *__restrict__ col, const double *__restrict__ val,
                                                                      const double *__restrict__ x, const double *__restrict__ yin,
@@ -1385,6 +1402,170 @@ static int setup_hot(phip_mat A, const int32_t *h_j, std::vector<int32_t> &order
   return 0;
 }
 
+/* ---- cold-column routing ---------------------------------------------------------------------------------------------------------
+   What bounds an irregular product once x outgrows L2 is not the 12 B/nonzero stream but the gathers that miss: each fills a 128-byte
+   line for 8 useful bytes, and no cache policy of the load fetches less (scripts/micro/gather_policy.hip: plain, sc0, sc1, nt alike;
+   R-MAT scale 22: 21 M line fills = 2.7 GB for 0.87 GB of algorithmic bytes).  The structure is static, so the library decides at
+   upload which columns are worth gathering -- the H most used, kept side by side as x' = x[rorder], small enough to stay in every
+   XCD's L2 -- and ROUTES the entries of all other columns to their nonzeros ahead of the product, by two passes that read and write
+   whole lines:
+     route_scatter_kernel   walks the cold nonzeros sorted by (column chunk, bin, column): a chunk's columns span a stretch of x that
+                            stays in L2 while the chunk is worked off (every line of x is fetched once, by one XCD: xcd_chunk_map), and
+                            inside a chunk the entries bound for one bin are stored side by side (runs of ~64 entries);
+     route_permute_kernel   one workgroup per bin of ROUTE_BIN = 8192 consecutive cold nonzeros (CSR order): the bin's 64 KiB go through
+                            LDS and come out in CSR order.
+   The row-block kernel itself does not change: it gathers from one array, xe = [x' | routed entries], with col' = hot rank or
+   Hpad + number of the cold nonzero -- the cold lanes of a wave read consecutive entries (one or two lines instead of one line each),
+   and the nonzeros, products and sums are the same in the same order: the same bits as without (test_cold_column_routing).
+   Traffic per cold nonzero: 16 B + 18 B + 8 B, all in whole lines, against a 128-byte fill.  Values never move: MatScale, MatShift,
+   phip_mat_update_values ... do not touch the routing.
+   Built for row-block (non-stencil) matrices when x has ROUTE_MIN_BYTES or more and the cold columns carry ROUTE_MIN_SHARE of the
+   nonzeros or more (PHIP_ROUTE / phip_set_default_route: 0 never, 1 by that rule, 2 whenever there are cold nonzeros;
+   PHIP_ROUTE_HOT / phip_set_route_hot_columns: H, default 262144 = 2 MiB of x'). */
+#define ROUTE_BIN 8192
+#define ROUTE_WG_ENTRIES 1024
+#define ROUTE_MIN_BYTES (24ll << 20)
+#define ROUTE_MIN_SHARE 0.05
+static int     g_route_mode = -1;
+static int32_t g_route_hot = -1;
+
+__global__ __launch_bounds__(256) void route_scatter_kernel(int64_t ncold, int nwg, const int2 *__restrict__ list, const double *__restrict__ x, double *__restrict__ tmp, int lc)
+{
+  const int64_t base = (int64_t)xcd_chunk_map((int)blockIdx.x, nwg, lc) * ROUTE_WG_ENTRIES + threadIdx.x;
+  int2          e[4];
+  double        v[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const int64_t p = base + 256 * u; e[u] = list[p < ncold ? p : ncold - 1]; } /* (a place behind the end repeats the last entry: same store twice) */
+#pragma unroll
+  for (int u = 0; u < 4; u++) v[u] = x[e[u].x];
+#pragma unroll
+  for (int u = 0; u < 4; u++) tmp[e[u].y] = v[u];
+}
+
+__global__ __launch_bounds__(1024) void route_permute_kernel(const double *__restrict__ tmp, const uint16_t *__restrict__ perm, double *__restrict__ out)
+{
+  __shared__ double stage[ROUTE_BIN];
+  const int64_t     b0 = (int64_t)blockIdx.x * ROUTE_BIN;
+  for (int i = threadIdx.x; i < ROUTE_BIN; i += 1024) stage[i] = __builtin_nontemporal_load(tmp + b0 + i);
+  __syncthreads();
+  for (int i = threadIdx.x; i < ROUTE_BIN; i += 1024) out[b0 + i] = stage[perm[b0 + i]];
+}
+
+static void free_route(phip_mat A)
+{
+  if (A->ctx->device >= 0) { hipFree(A->d_rcol); hipFree(A->d_rorder); hipFree(A->d_rlist); hipFree(A->d_rperm); hipFree(A->d_rtmp); hipFree(A->d_xe); }
+  A->d_rcol = NULL; A->d_rorder = NULL; A->d_rlist = NULL; A->d_rperm = NULL; A->d_rtmp = NULL; A->d_xe = NULL;
+  A->rt_built = 0; A->rt_on = 0; A->rt_ncold = 0; A->rt_nbins = 0;
+}
+
+static int setup_route(phip_mat A, const int32_t *h_j, std::vector<int32_t> &order, std::vector<int32_t> &newcol)
+{
+  free_route(A);
+  if (g_route_mode < 0) g_route_mode = getenv("PHIP_ROUTE") ? atoi(getenv("PHIP_ROUTE")) : 1;
+  if (g_route_hot < 0) g_route_hot = getenv("PHIP_ROUTE_HOT") ? atoi(getenv("PHIP_ROUTE_HOT")) : 262144;
+  const int mode = g_route_mode;
+  if (A->ctx->device < 0 || mode == 0 || A->nnz == 0 || A->n == 0 || A->sell_on) return 0;
+  const int32_t n = A->n;
+  const int64_t nnz = A->nnz;
+  if (mode != 2 && (int64_t)sizeof(double) * n < ROUTE_MIN_BYTES) return 0;
+  const int32_t H = std::max<int32_t>(0, std::min<int32_t>(n, g_route_hot));
+  if (H >= n) return 0;
+  if (order.size() != (size_t)n) column_use_order(h_j, nnz, n, order, newcol);
+  /* cold nonzeros per column -> their places in column order (a counting sort; inside a column the nonzeros keep their CSR order) */
+  std::vector<int64_t> cstart((size_t)n + 1, 0);
+  for (int64_t k = 0; k < nnz; k++) { const int32_t c = h_j[k]; if (newcol[(size_t)c] >= H) cstart[(size_t)c + 1]++; }
+  for (int32_t c = 0; c < n; c++) cstart[(size_t)c + 1] += cstart[(size_t)c];
+  const int64_t ncold = cstart[(size_t)n];
+  if (ncold == 0 || (mode != 2 && (double)ncold < ROUTE_MIN_SHARE * (double)nnz)) return 0;
+  PHIP_REQUIRE(ncold + (int64_t)H + 2 * ROUTE_BIN < ((int64_t)1 << 31), PHIP_ERR_ARG_OUTOFRANGE, "setup_route: %lld cold nonzeros do not fit 32-bit places", (long long)ncold);
+  const int32_t Hpad = (H + 15) & ~15;
+  const int32_t nbins = (int32_t)((ncold + ROUTE_BIN - 1) / ROUTE_BIN);
+  std::vector<int32_t> rcol((size_t)nnz + 8, 0);
+  std::vector<int32_t> cq((size_t)ncold), ccol((size_t)ncold); /* column order: number (CSR order) and column of each cold nonzero */
+  {
+    std::vector<int64_t> fill(cstart.begin(), cstart.end() - 1);
+    int64_t              q = 0;
+    for (int64_t k = 0; k < nnz; k++) {
+      const int32_t c = h_j[k], r = newcol[(size_t)c];
+      if (r < H) rcol[(size_t)k] = r;
+      else { rcol[(size_t)k] = Hpad + (int32_t)q; const int64_t p = fill[(size_t)c]++; cq[(size_t)p] = (int32_t)q; ccol[(size_t)p] = c; q++; }
+    }
+  }
+  /* column chunks: equal stretches of the column-ordered list, long enough that a chunk holds ~64 entries for every bin, a power of
+     two of workgroups each so that xcd_chunk_map keeps a chunk on one XCD */
+  int lc = 6;
+  while (lc < 12 && ((int64_t)ROUTE_WG_ENTRIES << lc) < 64 * (int64_t)nbins) lc++;
+  const int64_t CH = (int64_t)ROUTE_WG_ENTRIES << lc;
+  const int64_t nchunks = (ncold + CH - 1) / CH;
+  /* per chunk: histogram over the bins; per bin: where each chunk's run starts inside the bin (chunks in order) */
+  const int T = setup_threads(ncold);
+  std::vector<int32_t> hist((size_t)nchunks * (size_t)nbins, 0);
+  par_chunks(nchunks, T, [&](int, int64_t c0, int64_t c1) {
+    for (int64_t c = c0; c < c1; c++) {
+      int32_t *h = hist.data() + (size_t)c * (size_t)nbins;
+      for (int64_t p = c * CH; p < std::min(ncold, (c + 1) * CH); p++) h[(size_t)(cq[(size_t)p] / ROUTE_BIN)]++;
+    }
+  });
+  par_chunks(nbins, T, [&](int, int64_t b0, int64_t b1) { /* hist[c][b] := entries of bin b in the chunks before c */
+    for (int64_t b = b0; b < b1; b++) {
+      int32_t run = 0;
+      for (int64_t c = 0; c < nchunks; c++) { int32_t &h = hist[(size_t)c * (size_t)nbins + (size_t)b]; const int32_t t = h; h = run; run += t; }
+    }
+  });
+  std::vector<int2>     list((size_t)ncold);
+  std::vector<uint16_t> perm((size_t)nbins * ROUTE_BIN, 0);
+  par_chunks(nchunks, T, [&](int, int64_t c0, int64_t c1) {
+    std::vector<int64_t> lstart((size_t)nbins + 1);
+    for (int64_t c = c0; c < c1; c++) {
+      const int64_t p0 = c * CH, p1 = std::min(ncold, (c + 1) * CH);
+      /* places of the chunk's runs in the list: bins in order */
+      std::fill(lstart.begin(), lstart.end(), 0);
+      for (int64_t p = p0; p < p1; p++) lstart[(size_t)(cq[(size_t)p] / ROUTE_BIN) + 1]++;
+      for (int32_t b = 0; b < nbins; b++) lstart[(size_t)b + 1] += lstart[(size_t)b];
+      int32_t *inbin = hist.data() + (size_t)c * (size_t)nbins; /* next place inside each bin */
+      for (int64_t p = p0; p < p1; p++) { /* ascending column inside every run: p ascends */
+        const int32_t q = cq[(size_t)p], b = q / ROUTE_BIN;
+        const int32_t w = inbin[(size_t)b]++;
+        list[(size_t)(p0 + lstart[(size_t)b]++)] = make_int2(ccol[(size_t)p], b * ROUTE_BIN + w);
+        perm[(size_t)q] = (uint16_t)w;
+      }
+    }
+  });
+  hipStream_t st = A->ctx->stream;
+  const size_t nx = (size_t)Hpad + (size_t)nbins * ROUTE_BIN + 16;
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rcol, sizeof(int32_t) * rcol.size()));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rorder, sizeof(int32_t) * (size_t)std::max(H, 1)));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rlist, sizeof(int2) * list.size()));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rperm, sizeof(uint16_t) * perm.size()));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rtmp, sizeof(double) * (size_t)nbins * ROUTE_BIN));
+  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_xe, sizeof(double) * nx));
+  PHIP_CHECK_HIP(hipMemsetAsync(A->d_rtmp, 0, sizeof(double) * (size_t)nbins * ROUTE_BIN, st)); /* the places behind the last cold nonzero are read, never used */
+  PHIP_CHECK_HIP(hipMemsetAsync(A->d_xe, 0, sizeof(double) * nx, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_rcol, rcol.data(), sizeof(int32_t) * rcol.size(), hipMemcpyHostToDevice, st));
+  if (H) PHIP_CHECK_HIP(hipMemcpyAsync(A->d_rorder, order.data(), sizeof(int32_t) * (size_t)H, hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_rlist, list.data(), sizeof(int2) * list.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_rperm, perm.data(), sizeof(uint16_t) * perm.size(), hipMemcpyHostToDevice, st));
+  PHIP_CHECK_HIP(hipStreamSynchronize(st));
+  A->rt_H = H; A->rt_Hpad = Hpad; A->rt_ncold = ncold; A->rt_nbins = nbins; A->rt_lc = lc;
+  A->rt_built = 1; A->rt_on = 1;
+  return 0;
+}
+
+/* x -> xe: the hot entries in their order, the cold ones routed to their nonzeros (three launches on the product's stream) */
+static int launch_route(phip_mat A, const double *d_x)
+{
+  hipStream_t st = A->ctx->stream;
+  if (A->rt_H) {
+    const unsigned g = (unsigned)std::min<int64_t>(((int64_t)A->rt_H + 1023) / 1024, 16384);
+    hipLaunchKernelGGL(hot_gather_kernel, dim3(g), dim3(256), 0, st, A->rt_H, A->d_rorder, d_x, A->d_xe);
+  }
+  const int nwg = (int)((A->rt_ncold + ROUTE_WG_ENTRIES - 1) / ROUTE_WG_ENTRIES);
+  hipLaunchKernelGGL(route_scatter_kernel, dim3((unsigned)nwg), dim3(256), 0, st, A->rt_ncold, nwg, A->d_rlist, d_x, A->d_rtmp, A->rt_lc);
+  hipLaunchKernelGGL(route_permute_kernel, dim3((unsigned)A->rt_nbins), dim3(1024), 0, st, A->d_rtmp, A->d_rperm, A->d_xe + A->rt_Hpad);
+  PHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 /* ---- hot columns in LDS: set-up (spmv_wave_lds_kernel) ---------------------------------------------------------------------------
    OFF BY DEFAULT (PHIP_LDS_HOT / phip_set_default_lds_hot: 0 never = default, 1 by the rule below, 2 whenever the matrix has nonzeros).
    Measured on MI355X, R-MAT (profiles/r02_exp_rmat_lds.jsonl): scale 20 (57.6 % of the nonzeros in the K = 16 256 columns LDS holds)
@@ -2160,6 +2341,7 @@ extern "C" int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t
     std::vector<int32_t> order, newcol;
     if ((rc = setup_hot(A, h_j, order, newcol))) return rc;
     if ((rc = setup_lds(A, h_j, order, newcol))) return rc;
+    if ((rc = setup_route(A, h_j, order, newcol))) return rc;
   }
   clk.lap("hot columns");
   *out = A;
@@ -2355,6 +2537,7 @@ extern "C" int phip_mat_destroy(phip_mat A)
   free_sell(A);
   free_hot(A);
   free_lds(A);
+  free_route(A);
   delete A->h_sptr;
   hipFree(A->d_rowptr); hipFree(A->d_ridx); hipFree(A->d_col); hipFree(A->d_val); hipFree(A->d_blkrec);
   delete A->h_rowptr; delete A->h_blkrow; delete A->h_blktpr;
@@ -2519,12 +2702,18 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
       PHIP_CHECK_HIP(hipGetLastError());
       return 0;
     }
-    if (A->hot_on && A->nblocks) { /* x in the hot-column order (setup_hot) */
+    if (A->rt_built && A->rt_on && A->nblocks) { /* hot columns from x', cold ones routed to their nonzeros (setup_route) */
+      int rrc = launch_route(A, d_x);
+      if (rrc) return rrc;
+      cols = A->d_rcol; xs = A->d_xe;
+    } else if (A->hot_on && A->nblocks) { /* x in the hot-column order (setup_hot) */
       const unsigned g = (unsigned)std::min<int64_t>(((int64_t)A->n + 1023) / 1024, 16384);
       hipLaunchKernelGGL(hot_gather_kernel, dim3(g), dim3(256), 0, st, A->n, A->d_horder, d_x, A->d_hx);
       cols = A->d_hcol; xs = A->d_hx;
     }
-    const int xlc = (grid % 8 == 0 || !DOT) ? xcd_chunk_log2(XCD_CHUNK_LOG2_CSR) : 0; /* a strided grid keeps a workgroup on its XCD only if 8 divides it */
+    /* runs of 128 row blocks per XCD from 32 Ki blocks on, of 16 below: R-MAT scale 20 (10 400 blocks, the heavy rows in the first of them)
+       90.6 / 91.9 / 98.1 us with runs of 1 / 16 / 128 -- long runs put the expensive start of such a matrix on one XCD */
+    const int xlc = (grid % 8 == 0 || !DOT) ? xcd_chunk_log2(A->nblocks >= 32768 ? XCD_CHUNK_LOG2_CSR : 4) : 0; /* a strided grid keeps a workgroup on its XCD only if 8 divides it */
     if (csr_nt)
       hipLaunchKernelGGL((spmv_rowblock_kernel<DOT, true>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->nblocks, A->d_blkrec, A->d_rowptr, A->d_ridx, cols,
                          A->d_val, xs, d_yin, d_yout, add, A->use_cprow, d_v, ctl, xlc);
@@ -2786,6 +2975,37 @@ extern "C" int phip_set_dmask_kernel(int kind)
 {
   PHIP_REQUIRE(kind == 0 || kind == 4 || kind == 5 || kind == 6, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_dmask_kernel: %d (0 by size, 4 bit sets per row, 5 group descriptors, 6 group descriptors with x staged in LDS)", kind);
   g_dm_kernel = kind;
+  return 0;
+}
+
+extern "C" int phip_set_default_route(int mode)
+{
+  PHIP_REQUIRE(mode >= 0 && mode <= 2, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_default_route: %d (0 never, 1 when it pays, 2 whenever there are cold nonzeros)", mode);
+  g_route_mode = mode;
+  return 0;
+}
+extern "C" int phip_set_route_hot_columns(int32_t ncols)
+{
+  PHIP_REQUIRE(ncols >= 0, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_route_hot_columns: %d", ncols);
+  g_route_hot = ncols;
+  return 0;
+}
+extern "C" int phip_mat_set_route(phip_mat A, int on)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_set_route: null matrix");
+  PHIP_REQUIRE(!on || A->rt_built, PHIP_ERR_SUP, "phip_mat_set_route: no routing was built for this matrix");
+  A->rt_on = on ? 1 : 0;
+  if (A->T && A->T->rt_built) A->T->rt_on = A->rt_on;
+  return 0;
+}
+extern "C" int phip_mat_route_info(phip_mat A, int *built, int *in_use, int32_t *hot_columns, int64_t *cold_nonzeros, int32_t *bins)
+{
+  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_route_info: null matrix");
+  if (built) *built = A->rt_built;
+  if (in_use) *in_use = A->rt_built && A->rt_on && !A->sell_on;
+  if (hot_columns) *hot_columns = A->rt_built ? A->rt_H : 0;
+  if (cold_nonzeros) *cold_nonzeros = A->rt_built ? A->rt_ncold : 0;
+  if (bins) *bins = A->rt_built ? A->rt_nbins : 0;
   return 0;
 }
 

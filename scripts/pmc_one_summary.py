@@ -13,7 +13,7 @@ for f in glob.glob("%s/pmc_%s_*/**/*_counter_collection.csv" % (root, tag), recu
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if "spmv" in k or "hot_gather" in k or "panel" in k:
+        if "spmv" in k or "hot_gather" in k or "route" in k:
             d[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in d.items():
         out[k][c] = round(sum(v) / len(v), 1)

@@ -546,6 +546,92 @@ def test_hot_column_order(ctx, orc):
         ctx.check(L.phip_set_default_hot_columns(1))
 
 
+def test_cold_column_routing(ctx, orc):
+    """Cold-column routing (setup_route: the H most used columns gathered from x' = x[order], the entries of all other columns delivered
+    to their nonzeros in CSR order by a scatter into bins and a permutation of each bin) changes where an entry of x is read from and
+    nothing else: bit-identical results for mult, multadd, the fused dot, the transpose and the compressed-row form, for several H
+    (no hot column at all, a few, most), matrices with several bins and column chunks, rows longer than a row block, and a second
+    product with another x (no entry left over from the product before).  Small matrices get no routing unless it is forced."""
+    import ctypes as C
+    from petsc_amd import generators as G
+    from petsc_amd.capi import Ticket
+    L = ctx.lib
+    rng = np.random.default_rng(99)
+
+    def info(A):
+        b, u, h, nc, nb = C.c_int(), C.c_int(), C.c_int32(), C.c_int64(), C.c_int32()
+        ctx.check(L.phip_mat_route_info(A, C.byref(b), C.byref(u), C.byref(h), C.byref(nc), C.byref(nb)))
+        return b.value, u.value, h.value, nc.value, nb.value
+
+    ai, aj, aa = G.rmat(15)
+    n = len(ai) - 1
+    A = ctx.mat_create(n, n, ai, aj, aa)
+    assert info(A)[:2] == (0, 0)                      # default rule: x far too small
+    assert L.phip_mat_set_route(A, 1) != 0
+    ctx.check(L.phip_mat_destroy(A))
+    nz_rows = np.sort(rng.choice(5000, 600, replace=False)).astype(np.int32)
+    ri = np.zeros(5001, dtype=np.int32)
+    ri[nz_rows + 1] = rng.integers(1, 60, 600)
+    ri = np.cumsum(ri).astype(np.int32)
+    rj = np.concatenate([np.sort(rng.choice(30000, ri[r + 1] - ri[r], replace=False)) for r in range(5000)]).astype(np.int32)
+    ra = rng.standard_normal(len(rj))
+    cp = (np.concatenate([[0], np.cumsum(np.diff(ri)[nz_rows])]).astype(np.int32), nz_rows)
+    li = np.array([0, 3, 20003, 20004, 20004, 60004], dtype=np.int32)
+    lj = np.concatenate([[0, 2, 5], np.arange(20000), [7], np.arange(5, 40005)]).astype(np.int32)
+    la = rng.standard_normal(len(lj))
+    cases = [(ai, aj, aa, n, None), (ri, rj, ra, 30000, cp), (li, lj, la, 40010, None)]
+    ctx.check(L.phip_set_default_route(2))
+    try:
+        for H in (0, 37, 4096):
+            ctx.check(L.phip_set_route_hot_columns(H))
+            for ci, cj, ca, ncols, cprow in cases:
+                m = len(ci) - 1
+                xs = [rng.standard_normal(ncols), rng.standard_normal(ncols)]
+                v, y0 = rng.standard_normal(m), rng.standard_normal(m)
+                A = ctx.mat_create(m, ncols, ci, cj, ca, cprow)
+                built, used, h, ncold, nbins = info(A)
+                assert (built, used, h) == (1, 1, min(H, ncols)) and 0 < ncold <= len(cj) and nbins == (ncold + 8191) // 8192
+                if ci is ai:
+                    assert nbins >= 20 and (H > 0 or ncold == len(cj))
+                ctx.check(L.phip_mat_transpose_setup(A, ci.ctypes.data_as(C.POINTER(C.c_int32)), cj.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                     ca.ctypes.data_as(C.POINTER(C.c_double))))
+                dv, dy0 = ctx.to_device(v), ctx.to_device(y0)
+                dy, dz, dt, dd = (ctx.to_device(np.zeros(max(m, ncols))) for _ in range(4))
+                out = {}
+                for on in (1, 0):
+                    ctx.check(L.phip_mat_set_route(A, on))
+                    res = []
+                    for x in xs:
+                        dx = ctx.to_device(x)
+                        ctx.check(L.phip_mat_mult(A, dx, dy))
+                        ctx.check(L.phip_mat_multadd(A, dx, dy0, dz))
+                        t = Ticket()
+                        val = np.zeros(1)
+                        ctx.check(L.phip_mat_mult_dot(A, dx, dt, dv, 1, C.byref(t)))
+                        ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t), val.ctypes.data_as(C.POINTER(C.c_double))))
+                        res += [ctx.to_host(dy, m), ctx.to_host(dz, m), ctx.to_host(dt, m), val.copy()]
+                        ctx.free(dx)
+                    ctx.check(L.phip_mat_mult_transpose(A, dv, dt))
+                    res.append(ctx.to_host(dt, ncols))
+                    ctx.check(L.phip_mat_getdiagonal(A, dd))
+                    res.append(ctx.to_host(dd, m))
+                    out[on] = res
+                for a, b in zip(out[0], out[1]):
+                    np.testing.assert_array_equal(a, b)
+                assert relerr(out[1][0], orc.matmult(ci, cj, ca, xs[0])) <= 1e-12
+                for pz in (dv, dy0, dy, dz, dt, dd):
+                    ctx.free(pz)
+                ctx.check(L.phip_mat_destroy(A))
+        # the stencil layout has no use for it
+        si, sj, sa = G.laplace3d_7pt(12)
+        A = ctx.mat_create(len(si) - 1, len(si) - 1, si, sj, sa)
+        assert info(A)[:2] == (0, 0)
+        ctx.check(L.phip_mat_destroy(A))
+    finally:
+        ctx.check(L.phip_set_default_route(1))
+        ctx.check(L.phip_set_route_hot_columns(262144))
+
+
 def test_lds_hot_columns_wave_kernel(ctx, orc):
     """spmv_wave_lds_kernel (the K most used columns of x resident in LDS, one wave per block of rows): mult, multadd (also in place), the
     fused dot and the compressed-row form against the oracle (<= 1e-12; bit for bit with one lane per row) and against the row-block
