@@ -168,8 +168,7 @@ int phip_set_setup_threads(int nthreads);
 /* which of the two diagonal-mask kernels runs (same bits): 0 (default) by size -- spmv_dmaskg_kernel (group descriptors and transposed
  * masks read by the scalar unit, the masks as execution masks) from 4 Mi rows on or with 12 pairs and more, spmv_dmask4_kernel (a bit
  * set per row) otherwise --
- * 4 / 5: that kernel for every size; 6: spmv_dmasks_kernel, the group-descriptor kernel with the windows of x staged in LDS (a third of
- * the L1 traffic for a 27-point stencil, but measured slower: never chosen by itself).  PHIP_DMASK_KERNEL sets the initial value. */
+ * 4 / 5: that kernel for every size.  PHIP_DMASK_KERNEL sets the initial value. */
 int phip_set_dmask_kernel(int kind);
 /* tuning, process-wide: how the CSR row-block and SELL-dict kernels deal their work items (row blocks / slices) to the eight XCDs, each of
  * which has an L2 of its own: runs of `chunk` consecutive items per XCD (a power of two; 0 = the kernels' defaults, 128 row blocks / 8 slices;
@@ -182,9 +181,6 @@ int phip_set_xcd_chunk(int chunk);
 int phip_mat_mask_sets_info(phip_mat A, int64_t *nsets, int64_t *nwaves);
 int phip_mat_set_diag_mask(phip_mat A, int on);
 int phip_mat_diag_mask_info(phip_mat A, int *built, int *in_use, int32_t *npairs);
-/* tuning: SELL-dict kernel gathers x from LDS-staged contiguous segments (one per cluster of nearby diagonals) instead of through
- * L1/L2; same bits; measured slower on MI355X for 7- and 27-point stencils, hence off by default */
-int phip_mat_set_x_staging(phip_mat A, int on);
 /* tuning: loads of the matrix stream: -1 (default) non-temporal when the stream exceeds 192 MB (it would only displace x from the caches),
  * 0 always cached, 1 always non-temporal.  Same bits either way. */
 int phip_mat_set_nontemporal(phip_mat A, int mode);
@@ -202,32 +198,6 @@ int phip_set_default_hot_columns(int mode);
 int phip_mat_set_hot_columns(phip_mat A, int on);
 int phip_mat_hot_columns_info(phip_mat A, int *built, int *in_use, double *share_before, double *share_after);
 
-/* Cold-column routing of the CSR row-block layout, for irregular matrices whose x is far larger than L2.  A gather that misses L2 fills a
- * 128-byte line for 8 useful bytes, whatever the load's cache policy.  The library keeps the H most used columns as x' = x[order] (2 MiB:
- * they stay in every XCD's L2) and delivers the entries of all other columns to their nonzeros ahead of the product, in CSR order, by two
- * passes that move whole lines (a scatter by column chunk into bins, a permutation of each 64 KiB bin through LDS); the row-block kernel
- * then reads them as a stream.  Column indices are renumbered, nonzeros and values stay where they are, every row adds the same products
- * in the same order: same bits as without (no reference counterpart: MatMult_SeqAIJ, aij.c:1313-1320, gathers through the host's
- * caches).  Built at phip_mat_create when 8 n >= 24 MiB and the cold columns carry >= 5 % of the nonzeros (mode 1, the default;
- * PHIP_ROUTE or phip_set_default_route: 0 never, 2 whenever there are cold nonzeros); phip_set_route_hot_columns / PHIP_ROUTE_HOT: H
- * (default 262144); phip_mat_set_route switches a built routing off and on.  It takes precedence over the hot-column order above. */
-int phip_set_default_route(int mode);
-int phip_set_route_hot_columns(int32_t ncols);
-int phip_mat_set_route(phip_mat A, int on);
-int phip_mat_route_info(phip_mat A, int *built, int *in_use, int32_t *hot_columns, int64_t *cold_nonzeros, int32_t *bins);
-
-/* Hot columns resident in LDS, for the same kind of matrix (CSR row-block layout, columns used very unevenly): the K most used
- * columns (K = what 127 KiB of LDS hold, about 16 000) are copied from x into LDS by every workgroup of a persistent kernel (one
- * 1024-thread workgroup per CU) and gathered from there; a WAVE owns a block of rows (<= 254 nonzeros, <= 64 rows), sums each row with
- * 1..64 lanes out of an LDS stage of its own (one lane per row: k-ascending from 0.0 or y[i], the reference's bits).  A scattered
- * gather from LDS costs a wave a few clocks, from the caches about 3 clocks per lane.  EXPERIMENTAL AND OFF BY DEFAULT: exact, but on
- * R-MAT it is slower than the row-block kernel (16 waves per CU hide too little latency; very long rows are walked by one wave; numbers in
- * DESIGN.md).  PHIP_LDS_HOT or phip_set_default_lds_hot: 0 never (default), 1 build at phip_mat_create for matrices of 2^20 nonzeros and
- * more whose K columns carry >= 10 % of the nonzeros, 2 whenever there are nonzeros; phip_mat_set_lds_hot switches between this kernel
- * and the row-block kernel. */
-int phip_set_default_lds_hot(int mode);
-int phip_mat_set_lds_hot(phip_mat A, int on);
-int phip_mat_lds_hot_info(phip_mat A, int *built, int *in_use, int32_t *K, double *share);
 
 /* ---- vector kernels (the _VecOps slots, include/petsc/private/vecimpl.h:20-96) --------------------
  * n = local length.  Results of reductions are written to host memory and are valid on return.

@@ -55,7 +55,6 @@ SIGNATURES = [
     ("phip_mat_set_threads_per_row", C.c_int, [_vp, C.c_int32]),
     ("phip_set_default_mat_format", C.c_int, [C.c_int]),
     ("phip_mat_set_format", C.c_int, [_vp, C.c_int]),
-    ("phip_mat_set_x_staging", C.c_int, [_vp, C.c_int]),
     ("phip_mat_format_info", C.c_int, [_vp, C.POINTER(C.c_int), _pI, C.POINTER(C.c_int64)]),
     ("phip_set_default_value_dict", C.c_int, [C.c_int]),
     ("phip_mat_set_value_dict", C.c_int, [_vp, C.c_int]),
@@ -66,19 +65,12 @@ SIGNATURES = [
     ("phip_set_default_hot_columns", C.c_int, [C.c_int]),
     ("phip_mat_set_hot_columns", C.c_int, [_vp, C.c_int]),
     ("phip_mat_hot_columns_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pD, _pD]),
-    ("phip_set_default_lds_hot", C.c_int, [C.c_int]),
     ("phip_set_dmask_kernel", C.c_int, [C.c_int]),
     ("phip_set_xcd_chunk", C.c_int, [C.c_int]),
-    ("phip_set_default_route", C.c_int, [C.c_int]),
-    ("phip_set_route_hot_columns", C.c_int, [C.c_int32]),
-    ("phip_mat_set_route", C.c_int, [C.c_void_p, C.c_int]),
-    ("phip_mat_route_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     ("phip_set_setup_threads", C.c_int, [C.c_int]),
     ("phip_set_cg_defer_x", C.c_int, [C.c_int]),
     ("phip_mat_mask_sets_info", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("phip_halo_ipc_count", C.c_int, [C.POINTER(C.c_ulonglong)]),
-    ("phip_mat_set_lds_hot", C.c_int, [_vp, C.c_int]),
-    ("phip_mat_lds_hot_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pI, _pD]),
     ("phip_vec_dot", C.c_int, [_vp, C.c_int32, _vp, _vp, _pD]),
     ("phip_vec_norm", C.c_int, [_vp, C.c_int32, _vp, C.c_int, _pD]),
     ("phip_vec_mdot", C.c_int, [_vp, C.c_int32, _vp, C.c_int32, C.POINTER(_vp), _pD]),

@@ -53,9 +53,6 @@
 #define SELL_H 512             /* rows per SELL slice = 2 rows per lane */
 #define SELL_MAX_OFFS 256
 #define SELL_MAX_PAD 1.15
-#define SELL_CL_SPAN 64         /* diagonals at most this far apart share one staged x segment */
-#define SELL_CL_MAX 32
-#define SELL_STAGE_MAX_BYTES (64 * 1024)
 
 static int g_default_fmt = 0; /* phip_set_default_mat_format */
 /* The host passes of phip_mat_create (SELL-dict arrays, pair codes, masks) are independent per slice of rows: they run on
@@ -123,10 +120,6 @@ struct phip_mat_s {
   uint8_t *d_scode, *d_slen;
   int64_t *d_sptr;
   int32_t *d_soffs;
-  /* LDS staging of x for the SELL-dict kernel: diagonals grouped into clusters of nearby offsets, one contiguous x segment per cluster */
-  int      stage_ok, stage_user, stage_ncl, stage_lds_doubles;
-  int32_t *d_scl;     /* [ncl][3]: first offset of the cluster, start of its segment in LDS (doubles), segment length */
-  int32_t *d_sldsoff; /* [256]: LDS index of x[row + diagonal] for local row 0, per diagonal code */
   std::vector<int64_t> *h_sptr;
   /* pair dictionary of the SELL-dict layout (setup_pairs): one byte per stored entry names (diagonal, value) */
   int      vd_built, vd_on;
@@ -146,9 +139,6 @@ struct phip_mat_s {
   int       dm_dmin, dm_dmax; /* smallest / largest diagonal of the pair table */
   void     *d_gdesc;  /* [dm_ndesc + 3] DmGroup: the groups of spmv_dmaskg_kernel (at most one pair per place of the window) */
   int       dm_ndesc;
-  int32_t  *d_segs;   /* [dm_nseg][4] segments of spmv_dmasks_kernel: {first diagonal (even), entries of x to stage, first group, one behind the last} */
-  int       dm_nseg, dm_seg_maxlen, dm_smin, dm_smax; /* dm_nseg = 0: the staged kernel does not apply */
-  double    dm_l1_ratio; /* entries of x per row requested from the L1 by spmv_dmaskg_kernel / by the staged kernel */
   double   *d_dotpart; /* [4 S] the fused dot's partial sum of each wave (spmv_dmask_kernel<DOT>, summed by dot_wave_partials_kernel) */
   int32_t  *d_dmoffs; /* [32] */
   double   *d_dmvals; /* [32] */
@@ -165,30 +155,7 @@ struct phip_mat_s {
   int32_t *d_horder; /* [n] x'[k] = x[horder[k]] */
   double  *d_hx;     /* [n] x in the hot order, refilled by every product */
   double   hot_share[2]; /* share of the gathers that fall into the hottest HOT_LINES lines of x, before / after */
-  /* hot columns resident in LDS (spmv_wave_lds_kernel, setup_lds): the K most used columns get the slots 0..K-1 */
-  int      lds_built, lds_on;
-  int32_t  lds_K;
-  double   lds_share;   /* share of the nonzeros whose column is one of the K */
-  int32_t *d_lcol;      /* [nnz + pad] slot (< K) of a hot column, K + column otherwise; NULL when the hot-column order is built (d_hcol serves: hot columns come first in it) */
-  int32_t *d_hotlist;   /* [K] column of each slot */
-  int32_t *d_wbase;     /* [nwb + 1] rowptr[wblkrow[b]]: first nonzero of each wave block */
-  int32_t *d_wblkrow;   /* [nwb + 1] wave-block plan: block b = stored rows [wblkrow[b], wblkrow[b+1]) , <= WB_CAP nonzeros, <= 64 rows */
-  uint8_t *d_wblktpr;   /* [nwb] log2(lanes per row) of the block's reduce phase */
-  int32_t  nwb;
-  double  *d_wavepart;  /* fused dot: one partial per wave of the grid */
   int      nt_user;  /* phip_mat_set_nontemporal: -1 by size (default), 0 cached loads, 1 non-temporal loads of the matrix stream */
-  /* cold-column routing (setup_route): the x entries of rarely used columns are delivered to the nonzeros in CSR order, as a stream */
-  int       rt_built, rt_on;
-  int32_t   rt_H, rt_Hpad;   /* hot columns (gathered from x' = x[rorder]); Hpad = H rounded up to a line */
-  int64_t   rt_ncold;        /* nonzeros in cold columns */
-  int32_t   rt_nbins;        /* bins of ROUTE_BIN consecutive cold nonzeros (CSR order) */
-  int       rt_lc;           /* log2 of the workgroups that share a column chunk of the scatter list (XCD map) */
-  int32_t  *d_rcol;          /* [nnz + pad] hot rank of the column, or Hpad + number of the cold nonzero in CSR order */
-  int32_t  *d_rorder;        /* [H] column of each hot rank */
-  int2     *d_rlist;         /* [ncold] {column, place in rtmp}, sorted by (column chunk, bin, column) */
-  uint16_t *d_rperm;         /* [nbins * ROUTE_BIN] cold nonzero q finds its entry at rtmp[bin * ROUTE_BIN + rperm[q]] */
-  double   *d_rtmp;          /* [nbins * ROUTE_BIN] the routed entries, bin-major, inside a bin in list order */
-  double   *d_xe;            /* [Hpad + nbins * ROUTE_BIN + pad] what the row-block kernel gathers from: x' then the routed entries in CSR order */
 };
 
 /* Matrix entries are read once per launch.  When the matrix is much larger than the 256 MiB Infinity Cache, non-temporal loads keep
@@ -436,19 +403,17 @@ __global__ __launch_bounds__(PHIP_THREADS) SPMV_WAVES_ATTR void spmv_rowblock_ke
 }
 
 /* SELL-dict SpMV: see the header comment.  Lane t of slice b owns rows 512 b + 2 t and + 1.  DOT as in spmv_rowblock_kernel.
-   STAGE: the x entries a slice needs form a few contiguous segments (one per cluster of nearby diagonals: 9 for a 27-point stencil);
-   the workgroup copies them into LDS with coalesced loads and gathers from there, so each x entry crosses L2 once per cluster
-   instead of once per diagonal and the per-lane gathers no longer thrash L1. */
-template <bool NT, bool DOT, bool STAGE, int U>
+   (Rounds 1-2 carried a variant that staged the stretches of x a slice needs in LDS; measured slower every time -- 7-point 128^3
+   26.9 -> 31.8 us, 27-point 160^3 206 -> 220 us: the gathers are not what bounds this kernel -- and retired in round 3.) */
+template <bool NT, bool DOT, int U>
 __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int32_t n, int32_t nslices, const int64_t *__restrict__ sptr, const uint8_t *__restrict__ slen,
                                                                  const double *__restrict__ sval, const uint8_t *__restrict__ scode,
-                                                                 const int32_t *__restrict__ soffs, int noffs, const int32_t *__restrict__ scl, int ncl,
+                                                                 const int32_t *__restrict__ soffs, int noffs,
                                                                  const double *__restrict__ x, const double *__restrict__ yin, double *__restrict__ yout, int add,
                                                                  const double *__restrict__ dotv, RedCtl ctl, int nty, int xlc)
 {
 #pragma clang fp contract(off) /* multiply and add round separately, as the reference's compiled loop does (no FMA) */
-  extern __shared__ __attribute__((aligned(16))) double xs[]; /* STAGE: the x segments */
-  __shared__ int32_t offs[SELL_MAX_OFFS];                      /* diagonal (or, STAGE, LDS index) per code */
+  __shared__ int32_t offs[SELL_MAX_OFFS]; /* diagonal per code */
   __shared__ double  lds[4];
   const int t = threadIdx.x;
   offs[t] = (t < noffs) ? soffs[t] : 0;
@@ -456,17 +421,6 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
   double dacc = 0.0;
   for (int bi = blockIdx.x; bi < nslices; bi += gridDim.x) {
     const int b = xcd_chunk_map(bi, nslices, xlc);
-    if (STAGE) {
-      if (bi != (int)blockIdx.x) __syncthreads(); /* the previous slice of this workgroup is done with xs[] */
-      for (int c = 0; c < ncl; c++) {
-        const int g0 = b * SELL_H + scl[3 * c], s0 = scl[3 * c + 1], len = scl[3 * c + 2];
-        for (int i = t; i < len; i += PHIP_THREADS) {
-          const int g = g0 + i;
-          xs[s0 + i] = (g >= 0 && g < n) ? x[g] : 0.0;
-        }
-      }
-      __syncthreads();
-    }
     const int  r0 = b * SELL_H + 2 * t;
     const bool act = r0 < m;
     const bool has1 = r0 + 1 < m;
@@ -475,8 +429,8 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_sell_kernel(int32_t m, int3
     const int64_t  base = sptr[b];
     const double2 *vp = reinterpret_cast<const double2 *>(sval + base) + t;
     const uchar2  *cp = reinterpret_cast<const uchar2 *>(scode + base) + t;
-    const int      g0 = STAGE ? 2 * t : r0; /* STAGE: index into xs[] relative to the slice, else global row */
-    const double  *xv = STAGE ? xs : x;
+    const int      g0 = r0;
+    const double  *xv = x;
     double y0 = 0.0, y1 = 0.0;
     if (add && act) { y0 = yin[r0]; if (has1) y1 = yin[r0 + 1]; }
     double dv0 = 0.0, dv1 = 0.0; /* the fused dot's weights: requested here so that their latency hides behind the row sums */
@@ -621,82 +575,9 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_pair_kernel(int32_t m, int3
    nonzero, no code stream, no LDS table (diagonal and value of the current pair live in scalar registers).  Ascending diagonal is
    ascending column, so a row still adds its products k-ascending with separately rounded multiply and add: the reference's bits.
    Pairs no row of the wave holds are skipped; a wave whose 16-byte loads could leave x (first and last rows of the matrix, far
-   diagonals) takes the entries one by one. */
+   diagonals) takes the entries one by one.  (Round 1's kernel of this layout, two rows a lane, is retired: the two kernels below --
+   four rows a lane -- took its place in round 2.) */
 typedef double phip_v2d_u __attribute__((ext_vector_type(2), aligned(8)));
-
-template <bool DOT, int U>
-__global__ __launch_bounds__(PHIP_THREADS) void spmv_dmask_kernel(int32_t m, int32_t n, int32_t nslices, const uint32_t *__restrict__ rmask,
-                                                                  const int32_t *__restrict__ poffs, const double *__restrict__ pvals,
-                                                                  const double *__restrict__ x, const double *__restrict__ yin, double *__restrict__ yout,
-                                                                  int add, const double *__restrict__ dotv, double *__restrict__ wgpart, RedCtl ctl, int nty)
-{
-#pragma clang fp contract(off)
-  const int t = threadIdx.x;
-  double    dacc = 0.0;
-  for (int b = blockIdx.x; b < nslices; b += gridDim.x) {
-    const int   r0 = b * SELL_H + 2 * t;
-    const bool  actA = r0 < m, actB = r0 + 1 < m;
-    const uint2 mk = reinterpret_cast<const uint2 *>(rmask)[(size_t)b * (SELL_H / 2) + t];
-    const uint32_t mA = mk.x, mB = mk.y;
-    double yA = 0.0, yB = 0.0;
-    if (add) { if (actA) yA = yin[r0]; if (actB) yB = yin[r0 + 1]; }
-    double dvA = 0.0, dvB = 0.0;
-    if (DOT) { /* the fused dot's weights, one 16-byte load for the lane's two rows */
-      if (actB) { const phip_v2d_u q = *reinterpret_cast<const phip_v2d_u *>(dotv + r0); dvA = q.x; dvB = q.y; }
-      else if (actA) dvA = dotv[r0];
-    }
-    double sA = yA, sB = yB;
-    /* the pairs some row of this wave holds */
-    uint32_t um = mA | mB;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) um |= (uint32_t)__shfl_xor((int)um, o, 64);
-    uint32_t  rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)um);
-    const int w0 = b * SELL_H + (t & ~63) * 2; /* first of the 128 rows of this wave */
-    while (rem) {
-      int pp[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        if (rem) { pp[u] = __builtin_ctz(rem); rem &= rem - 1; }
-        else pp[u] = -1;
-      }
-      double xa[U], xb[U], vv[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        xa[u] = xb[u] = vv[u] = 0.0;
-        if (pp[u] >= 0) {
-          const int d = poffs[pp[u]];
-          vv[u] = pvals[pp[u]];
-          if (w0 + d >= 0 && (int64_t)w0 + 127 + d < (int64_t)n) { /* the whole wave stays inside x */
-            const phip_v2d_u q = *reinterpret_cast<const phip_v2d_u *>(x + (r0 + d));
-            xa[u] = q.x; xb[u] = q.y;
-          } else {
-            if ((mA >> pp[u]) & 1u) xa[u] = x[r0 + d];
-            if ((mB >> pp[u]) & 1u) xb[u] = x[r0 + 1 + d];
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        if (pp[u] >= 0) {
-          if ((mA >> pp[u]) & 1u) sA = sA + vv[u] * xa[u];
-          if ((mB >> pp[u]) & 1u) sB = sB + vv[u] * xb[u];
-        }
-      }
-    }
-    if (actB) {
-      st_result2(yout + r0, sA, sB, nty);
-    }
-    else if (actA) yout[r0] = sA;
-    if (DOT) {
-      if (actA) dacc += dvA * (sA - yA);
-      if (actB) dacc += dvB * (sB - yB);
-    }
-  }
-  if (DOT) { /* one partial per WAVE, stored and forgotten: no barrier, no wave waits for anything (dot_wave_partials_kernel sums them) */
-    const double s = wave_sum(dacc);
-    if ((t & 63) == 0) wgpart[(size_t)blockIdx.x * (PHIP_THREADS / 64) + (t >> 6)] = s;
-  }
-}
 
 /* The diagonal masks with FOUR adjacent rows per lane and the pairs taken in GROUPS of neighbouring diagonals.  spmv_dmask_kernel above
    still pushes every x entry through the vector L1 once per diagonal that touches it (27 times for a 27-point stencil): 216 B per row,
@@ -999,127 +880,6 @@ __global__ __launch_bounds__(PHIP_THREADS) void spmv_dmaskg_kernel(int32_t m, in
   }
 }
 
-/* spmv_dmaskg_kernel with the windows of x STAGED IN LDS.  What bounds spmv_dmaskg_kernel is the vector L1 (108 bytes requested per
-   row for 27 points): every group fetches its own window, six entries for four rows, although the groups of one plane of a stencil
-   (diagonals D, D + nx, D + 2 nx) walk over the same entries of x.  Here the groups are gathered into SEGMENTS of neighbouring
-   diagonals (host: setup_dmask); a workgroup (1024 rows) fetches the stretch of x a segment needs ONCE, coalesced and 16-byte aligned
-   -- 1024 + span entries, 12 KB for a plane of the 27-point 256^3 stencil: 36 bytes per row through the L1 for the three planes
-   instead of 108 -- and every lane takes its windows from LDS (128 bytes a clock).  The next segment's stretch is requested into
-   registers before the sums of this one begin.  Same descriptors, same transposed masks as execution masks, same sums in the same
-   order: the same bits.  MEASURED SLOWER, hence only behind phip_set_dmask_kernel(6): 27-point 256^3 108 us against 90 us
-   (132 us before the stretch was padded against bank conflicts): L1 accesses fall from 53.7 M to 16.4 M per launch as intended,
-   but a wave now issues 511 vector + 611 scalar + 70 LDS instructions (index arithmetic of the padded layout, barriers, staging)
-   against 297 + 476, and that is what the time follows (profiles/r02_pmc_spmv_dmasks.json).  smin / smax: first entry / one behind the last entry any segment touches relative to the workgroup's first
-   row: workgroups whose stretches stay inside x stage without range tests. */
-#define DMS_STAGE 4 /* 16-byte loads per thread and segment: stretches of up to 2048 entries */
-/* entry e of a stretch lives at LDS index e + e / 32: the lanes' windows start four entries (eight banks) apart, so without the padding
-   lanes l, l + 8, l + 16, l + 24 of a half-wave meet in the same banks (measured: 132 us against 90 us for the unstaged kernel) */
-#define DMS_PAD(e) ((e) + ((e) >> 5))
-template <bool DOT, bool ADD>
-__global__ __launch_bounds__(PHIP_THREADS) void spmv_dmasks_kernel(int32_t m, int32_t n, const DmWords *__restrict__ tmask, const int32_t *__restrict__ widx, const phip_u32x16 *__restrict__ gdesc,
-                                                                   const int4 *__restrict__ segs, int nseg, int smin, int smax, const double *__restrict__ x,
-                                                                   const double *__restrict__ yin, double *__restrict__ yout, const double *__restrict__ dotv,
-                                                                   double *__restrict__ wavepart, int nty)
-{
-#pragma clang fp contract(off)
-  extern __shared__ double lx[];
-  const int      t = threadIdx.x;
-  const int      wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (PHIP_THREADS / 64) + (t >> 6));
-  const int64_t  R0 = (int64_t)blockIdx.x * DMG_WG_ROWS;
-  const int      r0 = (int)R0 + DM4_ROWS * t;
-  const int      nact = m - r0; /* rows r0 .. r0 + 3 exist while i < nact */
-  double         y0[DM4_ROWS] = {0.0, 0.0, 0.0, 0.0}, s[DM4_ROWS];
-  if (ADD) {
-    if (nact >= DM4_ROWS) {
-      const phip_v2d_u a = *reinterpret_cast<const phip_v2d_u *>(yin + r0), b = *reinterpret_cast<const phip_v2d_u *>(yin + r0 + 2);
-      y0[0] = a.x; y0[1] = a.y; y0[2] = b.x; y0[3] = b.y;
-    } else {
-#pragma unroll
-      for (int i = 0; i < DM4_ROWS; i++) if (i < nact) y0[i] = yin[r0 + i];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < DM4_ROWS; i++) s[i] = y0[i];
-  const DmWords *tmw = tmask + (size_t)__builtin_amdgcn_readfirstlane(widx[wave]) * DMG_WORDS; /* the wave's set of mask words */
-  auto run = [&](auto fastc) {
-    constexpr bool FAST = decltype(fastc)::value;
-    phip_v2d_u st[DMS_STAGE];
-    /* the stretch of segment sg, two entries a thread and load, into registers */
-    auto fetch = [&](const int4 sg) {
-#pragma unroll
-      for (int k = 0; k < DMS_STAGE; k++) {
-        const int e = 2 * (t + PHIP_THREADS * k);
-        if (e < sg.y) {
-          if (FAST) st[k] = *reinterpret_cast<const phip_v2d_u *>(x + (R0 + sg.x + e));
-          else { /* clamped: an entry outside x is never used by a row's own pairs */
-            int64_t i0 = R0 + sg.x + e, i1 = i0 + 1;
-            i0 = i0 < 0 ? 0 : (i0 >= (int64_t)n ? (int64_t)n - 1 : i0);
-            i1 = i1 < 0 ? 0 : (i1 >= (int64_t)n ? (int64_t)n - 1 : i1);
-            st[k].x = x[i0]; st[k].y = x[i1];
-          }
-        }
-      }
-    };
-    auto put = [&](const int4 sg) {
-#pragma unroll
-      for (int k = 0; k < DMS_STAGE; k++) {
-        const int e = 2 * (t + PHIP_THREADS * k);
-        if (e < sg.y) { const int f = DMS_PAD(e); lx[f] = st[k].x; lx[f + 1] = st[k].y; } /* e is even: e and e + 1 share their padding */
-      }
-    };
-    int4    sg = segs[0];
-    DmGroup nxt = __builtin_bit_cast(DmGroup, gdesc[0]);
-    fetch(sg);
-    for (int si = 0; si < nseg; si++) {
-      put(sg);
-      __syncthreads();
-      const int4 cur = sg;
-      if (si + 1 < nseg) { sg = segs[si + 1]; fetch(sg); }
-      for (int g = cur.z; g < cur.w; g++) {
-        const DmGroup d = nxt;
-        nxt = __builtin_bit_cast(DmGroup, gdesc[g + 1]); /* the table has a spare descriptor behind the last group */
-        const DmWords m0 = tmw[d.q[0]], m1 = tmw[d.q[1]], m2 = tmw[d.q[2]];
-        asm volatile("" ::"s"(m0.w[0]), "s"(m0.w[1]), "s"(m0.w[2]), "s"(m0.w[3]), "s"(m1.w[0]), "s"(m1.w[1]), "s"(m1.w[2]), "s"(m1.w[3]));
-        asm volatile("" ::"s"(m2.w[0]), "s"(m2.w[1]), "s"(m2.w[2]), "s"(m2.w[3]));
-        const int e0 = DM4_ROWS * t + d.pad1[0]; /* pad1[0]: the group's base diagonal relative to its segment's */
-        double    w[DM4_WIN];
-#pragma unroll
-        for (int j = 0; j < DM4_WIN; j++) w[j] = lx[DMS_PAD(e0 + j)];
-        dmg_step<0>(s, w, d.v[0], m0);
-        if (d.span > 1) {
-          dmg_step<1>(s, w, d.v[1], m1);
-          dmg_step<2>(s, w, d.v[2], m2);
-        }
-      }
-      __syncthreads(); /* everybody is done with this stretch before the next one overwrites it */
-    }
-  };
-  if (R0 + smin >= 0 && R0 + smax <= (int64_t)n) run(std::true_type());
-  else run(std::false_type());
-  if (nact >= DM4_ROWS) {
-    st_result2(yout + r0, s[0], s[1], nty);
-    st_result2(yout + r0 + 2, s[2], s[3], nty);
-  } else {
-#pragma unroll
-    for (int i = 0; i < DM4_ROWS; i++) if (i < nact) yout[r0 + i] = s[i];
-  }
-  if (DOT) { /* one partial per wave, stored and forgotten (dot_wave_partials_kernel sums them); the weights are requested only now */
-    double dv[DM4_ROWS] = {0.0, 0.0, 0.0, 0.0};
-    if (nact >= DM4_ROWS) {
-      const phip_v2d_u a = *reinterpret_cast<const phip_v2d_u *>(dotv + r0), b = *reinterpret_cast<const phip_v2d_u *>(dotv + r0 + 2);
-      dv[0] = a.x; dv[1] = a.y; dv[2] = b.x; dv[3] = b.y;
-    } else {
-#pragma unroll
-      for (int i = 0; i < DM4_ROWS; i++) if (i < nact) dv[i] = dotv[r0 + i];
-    }
-    double dacc = 0.0;
-#pragma unroll
-    for (int i = 0; i < DM4_ROWS; i++) if (i < nact) dacc += dv[i] * (ADD ? s[i] - y0[i] : s[i]); /* MultAdd: the increment A x, not z */
-    dacc = wave_sum(dacc);
-    if ((t & 63) == 0) wavepart[(size_t)blockIdx.x * (PHIP_THREADS / 64) + (t >> 6)] = dacc;
-  }
-}
-
 /* second half of the fused dot of spmv_dmask_kernel: np wave partials, summed in a fixed order (thread t of workgroup b adds the entries
    (b * 256 + t) + k * gridDim.x * 256, k ascending, sixteen loads in flight; then block_sum and reduce_tail) and delivered as
    reduce_tail delivers */
@@ -1140,179 +900,6 @@ __global__ __launch_bounds__(PHIP_THREADS) void dot_wave_partials_kernel(const d
   block_sum<1>(a1, lds);
   __syncthreads();
   reduce_tail<1, 0>(a1, lds, c);
-}
-
-/* ---- hot columns resident in LDS -----------------------------------------------------------------------------------------------------
-   The row-block kernel above runs an irregular matrix at the rate of divergent gathers: every nonzero is one 8-byte load, the 64 lanes
-   of a wave instruction hit 64 different cache lines, and the texture path works them off line by line (about 3 clocks per gather and
-   CU even when every line is an L2 hit: DESIGN.md section 3, R-MAT).  LDS has no lines: a wave's 64 scattered 8-byte reads cost a few
-   clocks.  Power-law matrices spend a large share of their gathers on few columns (R-MAT scale 24: about 30 % on the 16 000 most used
-   of 16.8 M), so those entries of x are copied into LDS once per workgroup and gathered from there; only the rest goes through the
-   texture path.  For LDS to be shared by enough waves the kernel is persistent: ONE 1024-thread workgroup per CU fills its 127 KiB of
-   hot x and then its 16 waves walk the matrix independently of each other -- a WAVE, not a workgroup, owns a block of rows (<= WB_CAP
-   nonzeros, <= 64 rows), streams its values and columns coalesced, stages the products in 2 KiB of LDS of its own and sums each row with
-   1..64 lanes as spmv_reduce_rows does (one lane per row: k-ascending from 0.0 or y[i], the reference's bits).  No workgroup barrier
-   after the fill, so 16 waves hide each other's latency.  Column indices: c < K is an LDS slot, otherwise x_cold[c - coff]. */
-#define WB_CAP 254
-#define WB_STAGE 256
-#define WB_ROWS 64
-#define LDSK_THREADS 1024
-#define LDSK_WAVES (LDSK_THREADS / 64)
-
-/* row sums of one wave block out of the wave's LDS stage.  rpl: lane l holds rowptr[r0 + l] (the block has at most 64 rows; the entry
-   after the last row is `end`), so the row bounds come from a lane exchange instead of memory */
-template <int TPR, bool DOT>
-__device__ __forceinline__ void wave_reduce_rows(const double *prod, int rpl, int end, const int32_t *__restrict__ ridx, const double *__restrict__ yin,
-                                                 double *__restrict__ yout, int r0, int r1, int abase, bool add, bool cprow, const double *__restrict__ dotv,
-                                                 double &dacc, int lane)
-{
-  constexpr int RPP = 64 / TPR; /* rows per pass */
-  const int     nrows = r1 - r0;
-  const int     passes = (nrows + RPP - 1) / RPP;
-  const int     sub = lane % TPR;
-  for (int p = 0; p < passes; p++) {
-    const int  rr = p * RPP + lane / TPR;
-    const bool valid = rr < nrows;
-    const int  s0 = __shfl(rpl, rr & 63, 64), e0 = __shfl(rpl, (rr + 1) & 63, 64);
-    const int  s = valid ? s0 - abase : 0, e = valid ? (rr + 1 == nrows ? end : e0) - abase : 0;
-    const int  r = r0 + rr;
-    double     sum = 0.0;
-    if (TPR == 1) {
-      if (valid) {
-        const int    rout = cprow ? ridx[r] : r;
-        const double y0 = add ? yin[rout] : 0.0;
-        sum = lds_ordered_sum<1>(prod, s, e, y0);
-        yout[rout] = sum;
-        if (DOT) dacc += dotv[rout] * (add ? sum - y0 : sum);
-      }
-    } else {
-      sum = lds_ordered_sum<TPR>(prod, s + sub, e, 0.0);
-#pragma unroll
-      for (int o = TPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-      if (valid && sub == 0) {
-        const int rout = cprow ? ridx[r] : r;
-        if (DOT) dacc += dotv[rout] * sum;
-        if (add) sum += yin[rout];
-        yout[rout] = sum;
-      }
-    }
-  }
-}
-
-/* what a wave holds of a block before it works on it: requested one block ahead, so that the stream's latency hides behind the
-   gathers and row sums of the block before */
-struct WaveBlock {
-  int     r0, r1, base, end, tpr, rpl;
-  double2 a[2];
-  int2    c[2];
-};
-
-template <bool NT>
-__device__ __forceinline__ void wave_block_request(WaveBlock &B, int b, const int32_t *__restrict__ wblkrow, const int32_t *__restrict__ wbase, const uint8_t *__restrict__ wblktpr,
-                                                   const int32_t *__restrict__ rowptr, const int32_t *__restrict__ lcol, const double *__restrict__ val, int lane)
-{
-  B.r0 = wblkrow[b]; B.r1 = wblkrow[b + 1]; B.base = wbase[b]; B.end = wbase[b + 1]; B.tpr = wblktpr[b];
-  /* no tests around the loads (a test makes the wave wait for the load inside it -- the request would not run ahead of anything):
-     a lane behind the block's rows reads rowptr[r1] = end, a pair behind its end repeats the block's first pair */
-  const int nr = B.r1 - B.r0;
-  B.rpl = rowptr[B.r0 + (lane < nr ? lane : nr)];
-  const int abase = B.base & ~1; /* value pairs are 16-byte aligned */
-#pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const int e = abase + 2 * (lane + 64 * k), ec = (e < B.end && B.end - B.base <= WB_CAP) ? e : abase;
-    B.a[k] = ld_stream<NT>(reinterpret_cast<const double2 *>(val + ec));
-    B.c[k] = ld_stream<NT>(reinterpret_cast<const int2 *>(lcol + ec));
-  }
-}
-
-template <bool DOT, bool NT>
-__global__ __launch_bounds__(LDSK_THREADS) void spmv_wave_lds_kernel(int32_t nwb, const int32_t *__restrict__ wblkrow, const int32_t *__restrict__ wbase,
-                                                                     const uint8_t *__restrict__ wblktpr, const int32_t *__restrict__ rowptr,
-                                                                     const int32_t *__restrict__ ridx, const int32_t *__restrict__ lcol, const double *__restrict__ val,
-                                                                     const double *__restrict__ xhot, const int32_t *__restrict__ hotlist, int K,
-                                                                     const double *__restrict__ xcold, int coff, const double *__restrict__ yin,
-                                                                     double *__restrict__ yout, int add, int cprow, const double *__restrict__ dotv,
-                                                                     double *__restrict__ wavepart)
-{
-  extern __shared__ __attribute__((aligned(16))) double lds_all[]; /* [Kpad] hot x, then LDSK_WAVES stages of WB_STAGE products */
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int Kpad = (K + 1) & ~1;
-  const int gw = (int)blockIdx.x * LDSK_WAVES + w, nw = (int)gridDim.x * LDSK_WAVES;
-  WaveBlock cur, nxt;
-  if (gw < nwb) wave_block_request<NT>(cur, gw, wblkrow, wbase, wblktpr, rowptr, lcol, val, lane); /* in flight while LDS fills */
-  for (int k = t; k < K; k += LDSK_THREADS) lds_all[k] = hotlist ? xhot[hotlist[k]] : xhot[k];
-  __syncthreads();
-  double *prod = lds_all + Kpad + w * WB_STAGE;
-  double  dacc = 0.0;
-  /* both sources are read by every lane, without a test (a hot lane asks the cold side for its first entry, a cold lane LDS for slot 0),
-     and the value is selected afterwards: with a branch per gather the wave waited for each cold load on its own */
-  auto    X = [&](int c) -> double {
-    const bool   hot = c < K;
-    const double vl = lds_all[hot ? c : 0], vg = xcold[hot ? 0 : c - coff];
-    return hot ? vl : vg;
-  };
-  for (int b = gw; b < nwb; b += nw) {
-    if (b + nw < nwb) wave_block_request<NT>(nxt, b + nw, wblkrow, wbase, wblktpr, rowptr, lcol, val, lane);
-    if (cur.end - cur.base > WB_CAP) { /* one long row (the plan guarantees r1 == r0 + 1): the wave strides over it */
-      double        sum = 0.0;
-      constexpr int LU = 8; /* eight entries a lane requested together, added in the order of the plain loop */
-      for (int j0 = cur.base + lane; j0 < cur.end; j0 += LU * 64) {
-        int    cj[LU];
-        double vj[LU], xj[LU];
-#pragma unroll
-        for (int u = 0; u < LU; u++) {
-          const int j = j0 + u * 64, jc = j < cur.end ? j : cur.base;
-          cj[u] = lcol[jc];
-          vj[u] = val[jc];
-        }
-#pragma unroll
-        for (int u = 0; u < LU; u++) xj[u] = X(cj[u]);
-#pragma unroll
-        for (int u = 0; u < LU; u++) if (j0 + u * 64 < cur.end) sum += vj[u] * xj[u];
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-      if (lane == 0) {
-        const int rout = cprow ? ridx[cur.r0] : cur.r0;
-        if (DOT) dacc += dotv[rout] * sum;
-        if (add) sum += yin[rout];
-        yout[rout] = sum;
-      }
-    } else {
-      const int abase = cur.base & ~1;
-      double2 g[2];
-#pragma unroll
-      for (int k = 0; k < 2; k++) { g[k].x = X(cur.c[k].x); g[k].y = X(cur.c[k].y); } /* the four gathers of a lane together */
-#pragma unroll
-      for (int k = 0; k < 2; k++) { /* a pair behind the block's end leaves a product nobody reads */
-        double2 p;
-        p.x = cur.a[k].x * g[k].x;
-        p.y = cur.a[k].y * g[k].y;
-        *reinterpret_cast<double2 *>(prod + 2 * (lane + 64 * k)) = p;
-      }
-      /* the wave's own stage: its LDS accesses execute in order, the fences only keep the compiler from moving them */
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      switch (cur.tpr) {
-      case 0: wave_reduce_rows<1, DOT>(prod, cur.rpl, cur.end, ridx, yin, yout, cur.r0, cur.r1, abase, add, cprow, dotv, dacc, lane); break;
-      case 1: wave_reduce_rows<2, DOT>(prod, cur.rpl, cur.end, ridx, yin, yout, cur.r0, cur.r1, abase, add, cprow, dotv, dacc, lane); break;
-      case 2: wave_reduce_rows<4, DOT>(prod, cur.rpl, cur.end, ridx, yin, yout, cur.r0, cur.r1, abase, add, cprow, dotv, dacc, lane); break;
-      case 3: wave_reduce_rows<8, DOT>(prod, cur.rpl, cur.end, ridx, yin, yout, cur.r0, cur.r1, abase, add, cprow, dotv, dacc, lane); break;
-      case 4: wave_reduce_rows<16, DOT>(prod, cur.rpl, cur.end, ridx, yin, yout, cur.r0, cur.r1, abase, add, cprow, dotv, dacc, lane); break;
-      case 5: wave_reduce_rows<32, DOT>(prod, cur.rpl, cur.end, ridx, yin, yout, cur.r0, cur.r1, abase, add, cprow, dotv, dacc, lane); break;
-      default: wave_reduce_rows<64, DOT>(prod, cur.rpl, cur.end, ridx, yin, yout, cur.r0, cur.r1, abase, add, cprow, dotv, dacc, lane); break;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    cur = nxt;
-  }
-  if (DOT) { /* one partial per wave, summed by dot_wave_partials_kernel */
-    dacc = wave_sum(dacc);
-    if (lane == 0) wavepart[gw] = dacc;
-  }
 }
 
 __global__ void getdiag_kernel(int32_t m, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ ridx, int32_t R,
@@ -1399,299 +986,6 @@ static int setup_hot(phip_mat A, const int32_t *h_j, std::vector<int32_t> &order
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_horder, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipStreamSynchronize(st));
   A->hot_built = 1; A->hot_on = 1;
-  return 0;
-}
-
-/* ---- cold-column routing ---------------------------------------------------------------------------------------------------------
-   What bounds an irregular product once x outgrows L2 is not the 12 B/nonzero stream but the gathers that miss: each fills a 128-byte
-   line for 8 useful bytes, and no cache policy of the load fetches less (scripts/micro/gather_policy.hip: plain, sc0, sc1, nt alike;
-   R-MAT scale 22: 21 M line fills = 2.7 GB for 0.87 GB of algorithmic bytes).  The structure is static, so the library decides at
-   upload which columns are worth gathering -- the H most used, kept side by side as x' = x[rorder], small enough to stay in every
-   XCD's L2 -- and ROUTES the entries of all other columns to their nonzeros ahead of the product, by two passes that read and write
-   whole lines:
-     route_scatter_kernel   walks the cold nonzeros sorted by (column chunk, bin, column): a chunk's columns span a stretch of x that
-                            stays in L2 while the chunk is worked off (every line of x is fetched once, by one XCD: xcd_chunk_map), and
-                            inside a chunk the entries bound for one bin are stored side by side (runs of ~64 entries);
-     route_permute_kernel   one workgroup per bin of ROUTE_BIN = 8192 consecutive cold nonzeros (CSR order): the bin's 64 KiB go through
-                            LDS and come out in CSR order.
-   The row-block kernel itself does not change: it gathers from one array, xe = [x' | routed entries], with col' = hot rank or
-   Hpad + number of the cold nonzero -- the cold lanes of a wave read consecutive entries (one or two lines instead of one line each),
-   and the nonzeros, products and sums are the same in the same order: the same bits as without (test_cold_column_routing).
-   Traffic per cold nonzero: 16 B + 18 B + 8 B, all in whole lines, against a 128-byte fill.  Values never move: MatScale, MatShift,
-   phip_mat_update_values ... do not touch the routing.
-   Built for row-block (non-stencil) matrices when x has ROUTE_MIN_BYTES or more and the cold columns carry ROUTE_MIN_SHARE of the
-   nonzeros or more (PHIP_ROUTE / phip_set_default_route: 0 never, 1 by that rule, 2 whenever there are cold nonzeros;
-   PHIP_ROUTE_HOT / phip_set_route_hot_columns: H, default 262144 = 2 MiB of x'). */
-#define ROUTE_BIN 8192
-#define ROUTE_WG_ENTRIES 1024
-#define ROUTE_MIN_BYTES (24ll << 20)
-#define ROUTE_MIN_SHARE 0.05
-static int     g_route_mode = -1;
-static int32_t g_route_hot = -1;
-
-__global__ __launch_bounds__(256) void route_scatter_kernel(int64_t ncold, int nwg, const int2 *__restrict__ list, const double *__restrict__ x, double *__restrict__ tmp, int lc)
-{
-  const int64_t base = (int64_t)xcd_chunk_map((int)blockIdx.x, nwg, lc) * ROUTE_WG_ENTRIES + threadIdx.x;
-  int2          e[4];
-  double        v[4];
-#pragma unroll
-  for (int u = 0; u < 4; u++) { const int64_t p = base + 256 * u; e[u] = list[p < ncold ? p : ncold - 1]; } /* (a place behind the end repeats the last entry: same store twice) */
-#pragma unroll
-  for (int u = 0; u < 4; u++) v[u] = x[e[u].x];
-#pragma unroll
-  for (int u = 0; u < 4; u++) tmp[e[u].y] = v[u];
-}
-
-__global__ __launch_bounds__(1024) void route_permute_kernel(const double *__restrict__ tmp, const uint16_t *__restrict__ perm, double *__restrict__ out)
-{
-  __shared__ double stage[ROUTE_BIN];
-  const int64_t     b0 = (int64_t)blockIdx.x * ROUTE_BIN;
-  for (int i = threadIdx.x; i < ROUTE_BIN; i += 1024) stage[i] = __builtin_nontemporal_load(tmp + b0 + i);
-  __syncthreads();
-  for (int i = threadIdx.x; i < ROUTE_BIN; i += 1024) out[b0 + i] = stage[perm[b0 + i]];
-}
-
-static void free_route(phip_mat A)
-{
-  if (A->ctx->device >= 0) { hipFree(A->d_rcol); hipFree(A->d_rorder); hipFree(A->d_rlist); hipFree(A->d_rperm); hipFree(A->d_rtmp); hipFree(A->d_xe); }
-  A->d_rcol = NULL; A->d_rorder = NULL; A->d_rlist = NULL; A->d_rperm = NULL; A->d_rtmp = NULL; A->d_xe = NULL;
-  A->rt_built = 0; A->rt_on = 0; A->rt_ncold = 0; A->rt_nbins = 0;
-}
-
-static int setup_route(phip_mat A, const int32_t *h_j, std::vector<int32_t> &order, std::vector<int32_t> &newcol)
-{
-  free_route(A);
-  if (g_route_mode < 0) g_route_mode = getenv("PHIP_ROUTE") ? atoi(getenv("PHIP_ROUTE")) : 1;
-  if (g_route_hot < 0) g_route_hot = getenv("PHIP_ROUTE_HOT") ? atoi(getenv("PHIP_ROUTE_HOT")) : 262144;
-  const int mode = g_route_mode;
-  if (A->ctx->device < 0 || mode == 0 || A->nnz == 0 || A->n == 0 || A->sell_on) return 0;
-  const int32_t n = A->n;
-  const int64_t nnz = A->nnz;
-  if (mode != 2 && (int64_t)sizeof(double) * n < ROUTE_MIN_BYTES) return 0;
-  const int32_t H = std::max<int32_t>(0, std::min<int32_t>(n, g_route_hot));
-  if (H >= n) return 0;
-  if (order.size() != (size_t)n) column_use_order(h_j, nnz, n, order, newcol);
-  /* cold nonzeros per column -> their places in column order (a counting sort; inside a column the nonzeros keep their CSR order) */
-  std::vector<int64_t> cstart((size_t)n + 1, 0);
-  for (int64_t k = 0; k < nnz; k++) { const int32_t c = h_j[k]; if (newcol[(size_t)c] >= H) cstart[(size_t)c + 1]++; }
-  for (int32_t c = 0; c < n; c++) cstart[(size_t)c + 1] += cstart[(size_t)c];
-  const int64_t ncold = cstart[(size_t)n];
-  if (ncold == 0 || (mode != 2 && (double)ncold < ROUTE_MIN_SHARE * (double)nnz)) return 0;
-  PHIP_REQUIRE(ncold + (int64_t)H + 2 * ROUTE_BIN < ((int64_t)1 << 31), PHIP_ERR_ARG_OUTOFRANGE, "setup_route: %lld cold nonzeros do not fit 32-bit places", (long long)ncold);
-  const int32_t Hpad = (H + 15) & ~15;
-  const int32_t nbins = (int32_t)((ncold + ROUTE_BIN - 1) / ROUTE_BIN);
-  std::vector<int32_t> rcol((size_t)nnz + 8, 0);
-  std::vector<int32_t> cq((size_t)ncold), ccol((size_t)ncold); /* column order: number (CSR order) and column of each cold nonzero */
-  {
-    std::vector<int64_t> fill(cstart.begin(), cstart.end() - 1);
-    int64_t              q = 0;
-    for (int64_t k = 0; k < nnz; k++) {
-      const int32_t c = h_j[k], r = newcol[(size_t)c];
-      if (r < H) rcol[(size_t)k] = r;
-      else { rcol[(size_t)k] = Hpad + (int32_t)q; const int64_t p = fill[(size_t)c]++; cq[(size_t)p] = (int32_t)q; ccol[(size_t)p] = c; q++; }
-    }
-  }
-  /* column chunks: equal stretches of the column-ordered list, long enough that a chunk holds ~64 entries for every bin, a power of
-     two of workgroups each so that xcd_chunk_map keeps a chunk on one XCD */
-  int lc = 6;
-  while (lc < 12 && ((int64_t)ROUTE_WG_ENTRIES << lc) < 64 * (int64_t)nbins) lc++;
-  const int64_t CH = (int64_t)ROUTE_WG_ENTRIES << lc;
-  const int64_t nchunks = (ncold + CH - 1) / CH;
-  /* per chunk: histogram over the bins; per bin: where each chunk's run starts inside the bin (chunks in order) */
-  const int T = setup_threads(ncold);
-  std::vector<int32_t> hist((size_t)nchunks * (size_t)nbins, 0);
-  par_chunks(nchunks, T, [&](int, int64_t c0, int64_t c1) {
-    for (int64_t c = c0; c < c1; c++) {
-      int32_t *h = hist.data() + (size_t)c * (size_t)nbins;
-      for (int64_t p = c * CH; p < std::min(ncold, (c + 1) * CH); p++) h[(size_t)(cq[(size_t)p] / ROUTE_BIN)]++;
-    }
-  });
-  par_chunks(nbins, T, [&](int, int64_t b0, int64_t b1) { /* hist[c][b] := entries of bin b in the chunks before c */
-    for (int64_t b = b0; b < b1; b++) {
-      int32_t run = 0;
-      for (int64_t c = 0; c < nchunks; c++) { int32_t &h = hist[(size_t)c * (size_t)nbins + (size_t)b]; const int32_t t = h; h = run; run += t; }
-    }
-  });
-  std::vector<int2>     list((size_t)ncold);
-  std::vector<uint16_t> perm((size_t)nbins * ROUTE_BIN, 0);
-  par_chunks(nchunks, T, [&](int, int64_t c0, int64_t c1) {
-    std::vector<int64_t> lstart((size_t)nbins + 1);
-    for (int64_t c = c0; c < c1; c++) {
-      const int64_t p0 = c * CH, p1 = std::min(ncold, (c + 1) * CH);
-      /* places of the chunk's runs in the list: bins in order */
-      std::fill(lstart.begin(), lstart.end(), 0);
-      for (int64_t p = p0; p < p1; p++) lstart[(size_t)(cq[(size_t)p] / ROUTE_BIN) + 1]++;
-      for (int32_t b = 0; b < nbins; b++) lstart[(size_t)b + 1] += lstart[(size_t)b];
-      int32_t *inbin = hist.data() + (size_t)c * (size_t)nbins; /* next place inside each bin */
-      for (int64_t p = p0; p < p1; p++) { /* ascending column inside every run: p ascends */
-        const int32_t q = cq[(size_t)p], b = q / ROUTE_BIN;
-        const int32_t w = inbin[(size_t)b]++;
-        list[(size_t)(p0 + lstart[(size_t)b]++)] = make_int2(ccol[(size_t)p], b * ROUTE_BIN + w);
-        perm[(size_t)q] = (uint16_t)w;
-      }
-    }
-  });
-  hipStream_t st = A->ctx->stream;
-  const size_t nx = (size_t)Hpad + (size_t)nbins * ROUTE_BIN + 16;
-  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rcol, sizeof(int32_t) * rcol.size()));
-  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rorder, sizeof(int32_t) * (size_t)std::max(H, 1)));
-  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rlist, sizeof(int2) * list.size()));
-  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rperm, sizeof(uint16_t) * perm.size()));
-  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rtmp, sizeof(double) * (size_t)nbins * ROUTE_BIN));
-  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_xe, sizeof(double) * nx));
-  PHIP_CHECK_HIP(hipMemsetAsync(A->d_rtmp, 0, sizeof(double) * (size_t)nbins * ROUTE_BIN, st)); /* the places behind the last cold nonzero are read, never used */
-  PHIP_CHECK_HIP(hipMemsetAsync(A->d_xe, 0, sizeof(double) * nx, st));
-  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_rcol, rcol.data(), sizeof(int32_t) * rcol.size(), hipMemcpyHostToDevice, st));
-  if (H) PHIP_CHECK_HIP(hipMemcpyAsync(A->d_rorder, order.data(), sizeof(int32_t) * (size_t)H, hipMemcpyHostToDevice, st));
-  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_rlist, list.data(), sizeof(int2) * list.size(), hipMemcpyHostToDevice, st));
-  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_rperm, perm.data(), sizeof(uint16_t) * perm.size(), hipMemcpyHostToDevice, st));
-  PHIP_CHECK_HIP(hipStreamSynchronize(st));
-  A->rt_H = H; A->rt_Hpad = Hpad; A->rt_ncold = ncold; A->rt_nbins = nbins; A->rt_lc = lc;
-  A->rt_built = 1; A->rt_on = 1;
-  return 0;
-}
-
-/* x -> xe: the hot entries in their order, the cold ones routed to their nonzeros (three launches on the product's stream) */
-static int launch_route(phip_mat A, const double *d_x)
-{
-  hipStream_t st = A->ctx->stream;
-  if (A->rt_H) {
-    const unsigned g = (unsigned)std::min<int64_t>(((int64_t)A->rt_H + 1023) / 1024, 16384);
-    hipLaunchKernelGGL(hot_gather_kernel, dim3(g), dim3(256), 0, st, A->rt_H, A->d_rorder, d_x, A->d_xe);
-  }
-  const int nwg = (int)((A->rt_ncold + ROUTE_WG_ENTRIES - 1) / ROUTE_WG_ENTRIES);
-  hipLaunchKernelGGL(route_scatter_kernel, dim3((unsigned)nwg), dim3(256), 0, st, A->rt_ncold, nwg, A->d_rlist, d_x, A->d_rtmp, A->rt_lc);
-  hipLaunchKernelGGL(route_permute_kernel, dim3((unsigned)A->rt_nbins), dim3(1024), 0, st, A->d_rtmp, A->d_rperm, A->d_xe + A->rt_Hpad);
-  PHIP_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-/* ---- hot columns in LDS: set-up (spmv_wave_lds_kernel) ---------------------------------------------------------------------------
-   OFF BY DEFAULT (PHIP_LDS_HOT / phip_set_default_lds_hot: 0 never = default, 1 by the rule below, 2 whenever the matrix has nonzeros).
-   Measured on MI355X, R-MAT (profiles/r02_exp_rmat_lds.jsonl): scale 20 (57.6 % of the nonzeros in the K = 16 256 columns LDS holds)
-   391 us against 123 us for the row-block kernel, scale 22 (40.6 %) 1543 against 479 us (later, both kernels without tests around their
-   loads and long rows eight entries a lane: 170 against 89 us, 843 against 473 us) -- the few rows with tens of thousands of
-   nonzeros are walked by ONE wave each; with every row cut to 254 nonzeros 68.9 against 71.6 us: even then, with two thirds of the
-   gathers out of LDS, the kernel only draws level, because 16 waves a CU (what one 1024-thread workgroup per CU leaves) cannot hide
-   the chain stream -> gather -> stage -> row sums of a 254-nonzero block, requesting the next block's stream one block ahead
-   notwithstanding.  What it would take: two or three blocks of a wave in flight at once and long rows cut into chunks with a
-   deterministic second pass.  Kept, tested and switchable because its results are exact and the analysis is worth having.
-   Rule of mode 1: a row-block (non-stencil) matrix of 2^20 nonzeros or more whose K most used columns carry at least LDS_MIN_SHARE of
-   the nonzeros.  With the hot-column order of setup_hot in place its numbering is used as it is (the hot columns come first);
-   otherwise a column list of its own is built: slot of a hot column, K + column for the others, and x is gathered where it lies. */
-#define LDS_MIN_SHARE 0.10
-#define LDS_MIN_NNZ (1 << 20)
-static int g_lds_mode = -1;
-
-static void free_lds(phip_mat A)
-{
-  if (A->ctx->device >= 0) { hipFree(A->d_lcol); hipFree(A->d_hotlist); hipFree(A->d_wblkrow); hipFree(A->d_wblktpr); hipFree(A->d_wavepart); hipFree(A->d_wbase); }
-  A->d_wbase = NULL; A->d_lcol = NULL; A->d_hotlist = NULL; A->d_wblkrow = NULL; A->d_wblktpr = NULL; A->d_wavepart = NULL;
-  A->lds_built = 0; A->lds_on = 0; A->lds_K = 0; A->nwb = 0; A->lds_share = 0.0;
-}
-
-static uint8_t choose_tpr_log2_wave(int nrows, int maxlen)
-{
-  int best = 0, bestcost = 1 << 30;
-  for (int l = 0; l <= 6; l++) {
-    const int tpr = 1 << l, rpp = 64 / tpr;
-    const int cost = ((nrows + rpp - 1) / rpp) * (((maxlen + tpr - 1) / tpr) + 2) + 2 * l;
-    if (cost < bestcost) { bestcost = cost; best = l; }
-  }
-  return (uint8_t)best;
-}
-
-static void build_plan_wave(const std::vector<int32_t> &rp, int32_t R, int32_t tpr_user, std::vector<int32_t> &blkrow, std::vector<uint8_t> &blktpr)
-{
-  blkrow.clear(); blktpr.clear();
-  blkrow.push_back(0);
-  uint8_t forced = 255;
-  if (tpr_user > 0) { forced = 0; while ((1 << forced) < tpr_user && forced < 6) forced++; }
-  int32_t r = 0;
-  while (r < R) {
-    const int32_t start = r;
-    int32_t       len = rp[(size_t)r + 1] - rp[(size_t)r];
-    int           maxlen = 0;
-    if (len > WB_CAP) { r++; maxlen = len; }
-    else {
-      int64_t nnz = 0;
-      while (r < R && r - start < WB_ROWS) {
-        len = rp[(size_t)r + 1] - rp[(size_t)r];
-        if (nnz + len > WB_CAP) break;
-        nnz += len;
-        if (len > maxlen) maxlen = len;
-        r++;
-      }
-    }
-    blkrow.push_back(r);
-    blktpr.push_back(forced != 255 ? forced : choose_tpr_log2_wave(r - start, maxlen));
-  }
-}
-
-template <bool DOT, bool NT>
-static int lds_kernel_allow(size_t bytes)
-{
-  PHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_wave_lds_kernel<DOT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  return 0;
-}
-
-static int upload_plan_wave(phip_mat A)
-{
-  std::vector<int32_t> wblkrow;
-  std::vector<uint8_t> wblktpr;
-  build_plan_wave(*A->h_rowptr, A->R, A->tpr_user, wblkrow, wblktpr);
-  A->nwb = (int32_t)wblktpr.size();
-  hipStream_t st = A->ctx->stream;
-  if (A->d_wblkrow) { hipFree(A->d_wblkrow); A->d_wblkrow = NULL; }
-  if (A->d_wblktpr) { hipFree(A->d_wblktpr); A->d_wblktpr = NULL; }
-  if (A->d_wbase) { hipFree(A->d_wbase); A->d_wbase = NULL; }
-  std::vector<int32_t> wbase(wblkrow.size());
-  for (size_t b = 0; b < wblkrow.size(); b++) wbase[b] = (*A->h_rowptr)[(size_t)wblkrow[b]];
-  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_wbase, sizeof(int32_t) * wbase.size()));
-  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_wbase, wbase.data(), sizeof(int32_t) * wbase.size(), hipMemcpyHostToDevice, st));
-  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_wblkrow, sizeof(int32_t) * wblkrow.size()));
-  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_wblktpr, wblktpr.size() + 16));
-  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_wblkrow, wblkrow.data(), sizeof(int32_t) * wblkrow.size(), hipMemcpyHostToDevice, st));
-  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_wblktpr, wblktpr.data(), wblktpr.size(), hipMemcpyHostToDevice, st));
-  PHIP_CHECK_HIP(hipStreamSynchronize(st));
-  return 0;
-}
-
-static int setup_lds(phip_mat A, const int32_t *h_j, std::vector<int32_t> &order, std::vector<int32_t> &newcol)
-{
-  free_lds(A);
-  if (g_lds_mode < 0) g_lds_mode = getenv("PHIP_LDS_HOT") ? atoi(getenv("PHIP_LDS_HOT")) : 0; /* off by default: measured, see above */
-  const int mode = g_lds_mode;
-  if (A->ctx->device < 0 || mode == 0 || A->nnz == 0 || A->n == 0 || A->sell_on) return 0;
-  if (mode != 2 && A->nnz < LDS_MIN_NNZ) return 0;
-  int maxlds = 0;
-  PHIP_CHECK_HIP(hipDeviceGetAttribute(&maxlds, hipDeviceAttributeMaxSharedMemoryPerBlock, A->ctx->device));
-  const int64_t room = ((int64_t)maxlds - (int64_t)sizeof(double) * LDSK_WAVES * WB_STAGE - 1024) / (int64_t)sizeof(double);
-  if (room < 1024) return 0;
-  int32_t K = (int32_t)std::min<int64_t>(room & ~127ll, A->n);
-  if (order.empty()) column_use_order(h_j, A->nnz, A->n, order, newcol);
-  int64_t hot = 0;
-  for (int64_t k = 0; k < A->nnz; k++) hot += newcol[(size_t)h_j[k]] < K;
-  A->lds_share = (double)hot / (double)A->nnz;
-  if (mode != 2 && A->lds_share < LDS_MIN_SHARE) return 0;
-  A->lds_K = K;
-  hipStream_t st = A->ctx->stream;
-  if (!A->hot_built) { /* a column list of its own: slot of a hot column, K + column otherwise; x stays where it is */
-    std::vector<int32_t> lcol((size_t)A->nnz + 8, 0);
-    for (int64_t k = 0; k < A->nnz; k++) { const int32_t c = h_j[k], q = newcol[(size_t)c]; lcol[(size_t)k] = q < K ? q : K + c; }
-    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_lcol, sizeof(int32_t) * lcol.size()));
-    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_hotlist, sizeof(int32_t) * ((size_t)K + 4)));
-    PHIP_CHECK_HIP(hipMemcpyAsync(A->d_lcol, lcol.data(), sizeof(int32_t) * lcol.size(), hipMemcpyHostToDevice, st));
-    PHIP_CHECK_HIP(hipMemcpyAsync(A->d_hotlist, order.data(), sizeof(int32_t) * (size_t)K, hipMemcpyHostToDevice, st));
-    PHIP_CHECK_HIP(hipStreamSynchronize(st));
-  }
-  int rc = upload_plan_wave(A);
-  if (rc) return rc;
-  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_wavepart, sizeof(double) * ((size_t)A->ctx->cu_count * LDSK_WAVES + 16)));
-  const size_t bytes = sizeof(double) * ((size_t)((K + 1) & ~1) + (size_t)LDSK_WAVES * WB_STAGE);
-  if ((rc = lds_kernel_allow<false, false>(bytes)) || (rc = lds_kernel_allow<false, true>(bytes)) || (rc = lds_kernel_allow<true, false>(bytes)) ||
-      (rc = lds_kernel_allow<true, true>(bytes))) return rc;
-  A->lds_built = 1; A->lds_on = 1;
   return 0;
 }
 
@@ -1949,9 +1243,9 @@ static void free_pairs(phip_mat A)
 
 static void free_dmask(phip_mat A)
 {
-  if (A->ctx->device >= 0) { hipFree(A->d_rmask); hipFree(A->d_dmoffs); hipFree(A->d_dmvals); hipFree(A->d_dotpart); hipFree(A->d_dmgrp); hipFree(A->d_tmask); hipFree(A->d_widx); hipFree(A->d_gdesc); hipFree(A->d_segs); }
+  if (A->ctx->device >= 0) { hipFree(A->d_rmask); hipFree(A->d_dmoffs); hipFree(A->d_dmvals); hipFree(A->d_dotpart); hipFree(A->d_dmgrp); hipFree(A->d_tmask); hipFree(A->d_widx); hipFree(A->d_gdesc); }
   A->d_widx = NULL; A->dm_nsets = 0;
-  A->d_tmask = NULL; A->d_gdesc = NULL; A->dm_ndesc = 0; A->d_segs = NULL; A->dm_nseg = 0;
+  A->d_tmask = NULL; A->d_gdesc = NULL; A->dm_ndesc = 0;
   A->d_rmask = NULL; A->d_dmoffs = NULL; A->d_dmvals = NULL; A->d_dotpart = NULL; A->d_dmgrp = NULL; A->dm_ngroups = 0; A->dm_built = 0; A->dm_on = 0; A->dm_npairs = 0;
 }
 
@@ -2025,27 +1319,6 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
   }
   A->dm_dmin = offs[0]; A->dm_dmax = offs[npairs - 1];
   A->dm_ndesc = ndesc;
-  /* segments of spmv_dmasks_kernel: consecutive groups whose diagonals lie within a stretch of at most 2048 entries for 1024 rows */
-  int32_t segs[DMASK_MAX_PAIRS][4];
-  int     nseg = 0, maxlen = 0, smin = 0, smax = 0;
-  double  direct = 0.0, staged = 0.0;
-  for (int g = 0; g < ndesc;) {
-    const int32_t D0 = gd[g].D & ~1; /* even: the staging loads are 16-byte aligned */
-    int           e = g;
-    int64_t       last = (int64_t)gd[g].D + DM4_SPAN - 1;
-    while (e + 1 < ndesc && (int64_t)gd[e + 1].D + DM4_SPAN - 1 - D0 + DMG_WG_ROWS + 2 <= 2 * PHIP_THREADS * DMS_STAGE) { e++; last = (int64_t)gd[e].D + DM4_SPAN - 1; }
-    const int64_t len64 = (last - D0 + DMG_WG_ROWS + 2) & ~(int64_t)1;
-    if (len64 > 2 * PHIP_THREADS * DMS_STAGE) { nseg = 0; break; } /* a single group cannot exceed it: 1024 + 4 entries */
-    for (int h = g; h <= e; h++) { gd[h].pad1[0] = gd[h].D - D0; direct += gd[h].span > 1 ? 6.0 / 4.0 : 1.0; }
-    segs[nseg][0] = D0; segs[nseg][1] = (int32_t)len64; segs[nseg][2] = g; segs[nseg][3] = e + 1;
-    staged += (double)len64 / DMG_WG_ROWS;
-    if (!nseg || D0 < smin) smin = D0;
-    if (!nseg || D0 + (int32_t)len64 > smax) smax = D0 + (int32_t)len64;
-    if ((int)len64 > maxlen) maxlen = (int)len64;
-    nseg++;
-    g = e + 1;
-  }
-  A->dm_nseg = nseg; A->dm_seg_maxlen = maxlen; A->dm_smin = smin; A->dm_smax = smax; A->dm_l1_ratio = staged > 0.0 ? direct / staged : 0.0;
   /* the transposed masks: one wave = 256 rows, lane l holds the rows 4 l .. 4 l + 3 of them (words 0 .. 3); entry DMASK_MAX_PAIRS of
      a wave stays empty (the places of a window that carry no pair) */
   const size_t nwaves = (((size_t)A->m + DMG_WG_ROWS - 1) / DMG_WG_ROWS) * (PHIP_THREADS / 64);
@@ -2097,7 +1370,6 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_widx, sizeof(int32_t) * widx.size()));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_tmask, sizeof(unsigned long long) * tmask.size()));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_gdesc, sizeof(gd)));
-    PHIP_CHECK_HIP(hipMalloc((void **)&A->d_segs, sizeof(segs)));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dmgrp, sizeof(grp)));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_rmask, sizeof(uint32_t) * rmask.size()));
     PHIP_CHECK_HIP(hipMalloc((void **)&A->d_dmoffs, sizeof(offs)));
@@ -2108,7 +1380,6 @@ static int setup_dmask(phip_mat A, const std::vector<uint8_t> &pcode, const std:
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_tmask, tmask.data(), sizeof(unsigned long long) * std::max<size_t>(nsets, 1) * setw, hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_widx, widx.data(), sizeof(int32_t) * widx.size(), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_gdesc, gd, sizeof(gd), hipMemcpyHostToDevice, st));
-  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_segs, segs, sizeof(segs), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmoffs, offs, sizeof(offs), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmvals, vals, sizeof(vals), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_dmgrp, grp, sizeof(grp), hipMemcpyHostToDevice, st));
@@ -2180,8 +1451,8 @@ static void free_sell(phip_mat A)
   free_pairs(A);
   delete A->h_scode; A->h_scode = NULL;
   delete A->h_soffs; A->h_soffs = NULL;
-  if (A->ctx->device >= 0) { hipFree(A->d_sval); hipFree(A->d_scode); hipFree(A->d_slen); hipFree(A->d_sptr); hipFree(A->d_soffs); hipFree(A->d_scl); hipFree(A->d_sldsoff); }
-  A->d_sval = NULL; A->d_scode = NULL; A->d_slen = NULL; A->d_sptr = NULL; A->d_soffs = NULL; A->d_scl = NULL; A->d_sldsoff = NULL; A->stage_ok = 0;
+  if (A->ctx->device >= 0) { hipFree(A->d_sval); hipFree(A->d_scode); hipFree(A->d_slen); hipFree(A->d_sptr); hipFree(A->d_soffs); }
+  A->d_sval = NULL; A->d_scode = NULL; A->d_slen = NULL; A->d_sptr = NULL; A->d_soffs = NULL;
   A->sell_on = 0; A->sell_built = 0;
 }
 
@@ -2209,29 +1480,6 @@ static int setup_sell(phip_mat A, const int32_t *h_j, const double *h_a)
   A->sell_maxlen = 0;
   for (int32_t r = 0; r < A->R; r++) { const int32_t L = (*A->h_rowptr)[(size_t)r + 1] - (*A->h_rowptr)[(size_t)r]; if (L > A->sell_maxlen) A->sell_maxlen = L; }
   A->sell_on = 1; A->sell_built = 1;
-  /* x staging plan: sort the diagonals, cut into clusters no wider than SELL_CL_SPAN, one LDS segment of SELL_H + width per cluster */
-  std::vector<int32_t> scl, sldsoff(SELL_MAX_OFFS, 0);
-  {
-    std::vector<int> order(soffs.size());
-    for (size_t q = 0; q < order.size(); q++) order[q] = (int)q;
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return soffs[(size_t)a] < soffs[(size_t)b]; });
-    int total = 0;
-    size_t q = 0;
-    while (q < order.size()) {
-      const int32_t first = soffs[(size_t)order[q]];
-      size_t        e = q;
-      while (e + 1 < order.size() && (int64_t)soffs[(size_t)order[e + 1]] - first <= SELL_CL_SPAN) e++;
-      const int32_t width = soffs[(size_t)order[e]] - first;
-      const int     len = SELL_H + width;
-      for (size_t k = q; k <= e; k++) sldsoff[(size_t)order[k]] = total + (soffs[(size_t)order[k]] - first);
-      scl.push_back(first); scl.push_back(total); scl.push_back(len);
-      total += (len + 1) & ~1;
-      q = e + 1;
-    }
-    A->stage_ncl = (int)(scl.size() / 3);
-    A->stage_lds_doubles = total;
-    A->stage_ok = A->stage_ncl <= SELL_CL_MAX && (size_t)total * sizeof(double) <= SELL_STAGE_MAX_BYTES;
-  }
   if (A->ctx->device < 0) return 0;
   hipStream_t st = A->ctx->stream;
   PHIP_CHECK_HIP(hipMalloc((void **)&A->d_sval, sizeof(double) * sval.size()));
@@ -2245,10 +1493,6 @@ static int setup_sell(phip_mat A, const int32_t *h_j, const double *h_a)
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_slen, slen.data(), slen.size(), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_sptr, A->h_sptr->data(), sizeof(int64_t) * A->h_sptr->size(), hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipMemcpyAsync(A->d_soffs, soffs.data(), sizeof(int32_t) * SELL_MAX_OFFS, hipMemcpyHostToDevice, st));
-  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_scl, sizeof(int32_t) * (scl.size() + 4)));
-  PHIP_CHECK_HIP(hipMalloc((void **)&A->d_sldsoff, sizeof(int32_t) * SELL_MAX_OFFS));
-  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_scl, scl.data(), sizeof(int32_t) * scl.size(), hipMemcpyHostToDevice, st));
-  PHIP_CHECK_HIP(hipMemcpyAsync(A->d_sldsoff, sldsoff.data(), sizeof(int32_t) * SELL_MAX_OFFS, hipMemcpyHostToDevice, st));
   PHIP_CHECK_HIP(hipStreamSynchronize(st));
   clk.lap("  SELL arrays to the device");
   int rc = setup_pairs(A, scode, sval, soffs);
@@ -2340,8 +1584,6 @@ extern "C" int phip_mat_create(phip_ctx ctx, int32_t m, int32_t n, const int32_t
   {
     std::vector<int32_t> order, newcol;
     if ((rc = setup_hot(A, h_j, order, newcol))) return rc;
-    if ((rc = setup_lds(A, h_j, order, newcol))) return rc;
-    if ((rc = setup_route(A, h_j, order, newcol))) return rc;
   }
   clk.lap("hot columns");
   *out = A;
@@ -2536,8 +1778,6 @@ extern "C" int phip_mat_destroy(phip_mat A)
   hipStreamSynchronize(A->ctx->stream);
   free_sell(A);
   free_hot(A);
-  free_lds(A);
-  free_route(A);
   delete A->h_sptr;
   hipFree(A->d_rowptr); hipFree(A->d_ridx); hipFree(A->d_col); hipFree(A->d_val); hipFree(A->d_blkrec);
   delete A->h_rowptr; delete A->h_blkrow; delete A->h_blktpr;
@@ -2563,16 +1803,10 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
        192^3, 57 MB: no change).  PHIP_SPMV_NT_Y=0|1 overrides. */
     static const int nty_env = getenv("PHIP_SPMV_NT_Y") ? atoi(getenv("PHIP_SPMV_NT_Y")) : -1;
     const int        nty = nty_env >= 0 ? nty_env : (A->m >= (8 << 20));
-    /* LDS staging of x is correct but measured SLOWER than gathering through L1/L2 (7-point 128^3: 26.9 -> 31.8 us; 27-point 160^3:
-       206 -> 220 us; with values from the pair dictionary instead of the stream, 27-point 256^3: 327 -> 539 us): the gathers are not
-       what bounds this kernel.  Off unless PHIP_SELL_STAGE=1. */
-    static const int stage_env = getenv("PHIP_SELL_STAGE") ? atoi(getenv("PHIP_SELL_STAGE")) : 0;
-    const bool     stage = A->stage_ok && (stage_env != 0 || A->stage_user);
-    const bool     vd = A->vd_built && A->vd_on && !stage; /* the pair dictionary has a kernel of its own; the x-staging knob belongs to spmv_sell_kernel */
-#define SELL_LAUNCH2(NTv, STv, Uv)                                                                                                                        \
-  hipLaunchKernelGGL((spmv_sell_kernel<NTv, DOT, STv, Uv>), dim3(grid), dim3(PHIP_THREADS), (STv) ? sizeof(double) * (size_t)A->stage_lds_doubles : 0, st, A->m, \
-                     A->n, A->sell_nslices, A->d_sptr, A->d_slen, A->d_sval, A->d_scode, (STv) ? A->d_sldsoff : A->d_soffs, A->sell_noffs, A->d_scl,      \
-                     A->stage_ncl, d_x, d_yin, d_yout, add, d_v, ctl, nty, sxlc)
+    const bool     vd = A->vd_built && A->vd_on; /* the pair dictionary has a kernel of its own */
+#define SELL_LAUNCH2(NTv, Uv)                                                                                                                             \
+  hipLaunchKernelGGL((spmv_sell_kernel<NTv, DOT, Uv>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_sptr, A->d_slen, A->d_sval,    \
+                     A->d_scode, A->d_soffs, A->sell_noffs, d_x, d_yin, d_yout, add, d_v, ctl, nty, sxlc)
     /* slots requested per lane before the gathers start: 8 for long rows (27-point 192^3: 361.9 -> 349.7 us), 4 otherwise (rows of 7
        never fill a batch of 8: 27.1 -> 36.1 us); PHIP_SELL_UNROLL=4|8 overrides */
     static const int unroll_env = getenv("PHIP_SELL_UNROLL") ? atoi(getenv("PHIP_SELL_UNROLL")) : 0;
@@ -2580,7 +1814,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
        (27-point 256^3 inside KSPCG: 926 us against 903 us with batches of 4).  Also tried and dropped: taking the fused dot's weight
        x[r] from the row's own diagonal gather instead of a second load (256^3: 903 -> 967 us, the per-slot test costs more) */
     const int        unroll = unroll_env ? unroll_env : ((A->sell_maxlen >= 16 && !DOT) ? 8 : 4);
-#define SELL_LAUNCH(NTv, STv) do { if (unroll == 8) SELL_LAUNCH2(NTv, STv, 8); else SELL_LAUNCH2(NTv, STv, 4); } while (0)
+#define SELL_LAUNCH(NTv) do { if (unroll == 8) SELL_LAUNCH2(NTv, 8); else SELL_LAUNCH2(NTv, 4); } while (0)
     /* groups of 4 slots requested per lane before their gathers start: 2 for short rows, 1 for long ones (7-point 128^3 inside KSPCG
        16.19 k -> 16.34 k it/s with 2; 27-point 256^3 SpMV 327 -> 300 us with 1); PHIP_PAIR_GROUPS=1|2 overrides */
     static const int pair_g_env = getenv("PHIP_PAIR_GROUPS") ? atoi(getenv("PHIP_PAIR_GROUPS")) : 0;
@@ -2595,33 +1829,20 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
        (write-through store, wait, atomic with return: ~4 us per workgroup) the same, and 7-point 128^3 27 us against 13.6 us.
        PHIP_DMASK_DOT=0 sends the fused-dot products to the pair-code kernel instead (round 1's rule for matrices under 40 M nonzeros;
        with four rows a lane the masks win there too: 7-point 128^3 fused-dot product 13.9 us against 16.1 us). */
-    static const int dm_u_env = getenv("PHIP_DMASK_UNROLL") ? atoi(getenv("PHIP_DMASK_UNROLL")) : 0;
     static const int dm_dot_env = getenv("PHIP_DMASK_DOT") ? atoi(getenv("PHIP_DMASK_DOT")) : -1;
     if (vd && A->dm_built && A->dm_on && (!DOT || g_dm_mode == 2 || dm_dot_env != 0)) {
       double        *part = DOT ? A->d_dotpart : NULL;
-      /* four rows a lane and grouped diagonals (spmv_dmask4_kernel) unless PHIP_DMASK_ROWS=2 asks for the two-row kernel */
-      static const int dm_rows_env = getenv("PHIP_DMASK_ROWS") ? atoi(getenv("PHIP_DMASK_ROWS")) : 4;
       static const int dm_ug_env = getenv("PHIP_DMASK_GROUPS") ? atoi(getenv("PHIP_DMASK_GROUPS")) : 0;
       int              nwg;
       /* spmv_dmaskg_kernel from 4 Mi rows on and for matrices with 12 pairs and more, spmv_dmask4_kernel otherwise (27-point 256^3:
          116 -> 87 us with the former, 27-point 128^3 21.2 -> 15.9 us and KSPCG 13.95 k -> 14.96 k it/s; 7-point 128^3 inside KSPCG 1 %
          better with the latter: its launches are 10 us long and start from cold scalar caches);
-         PHIP_DMASK_KERNEL / phip_set_dmask_kernel: 4 or 5 (the group-descriptor kernel) for all sizes */
+         PHIP_DMASK_KERNEL / phip_set_dmask_kernel: 4 or 5 (the group-descriptor kernel) for all sizes.  Retired in round 3 after two
+         rounds behind switches, measured slower: round 1's two-rows-a-lane kernel (27-point 256^3 205 us against 116 / 87 us) and the
+         group-descriptor kernel with its windows staged in LDS (108 us against 90 us); both are in the history. */
       if (g_dm_kernel < 0) g_dm_kernel = getenv("PHIP_DMASK_KERNEL") ? atoi(getenv("PHIP_DMASK_KERNEL")) : 0;
-      const bool use_g = g_dm_kernel == 5 || (g_dm_kernel != 4 && g_dm_kernel != 6 && (A->m >= DMG_MIN_ROWS || A->dm_npairs >= 12));
-      /* 6: the same with the windows staged in LDS (spmv_dmasks_kernel); requests dm_l1_ratio times fewer entries from the L1 (27-point:
-         3 x) but measured slower, so never by default */
-      const bool use_s = A->dm_nseg > 0 && g_dm_kernel == 6;
-      if (dm_rows_env != 2 && use_s) {
-        nwg = (A->m + DMG_WG_ROWS - 1) / DMG_WG_ROWS;
-        const size_t lds = sizeof(double) * (size_t)(DMS_PAD(A->dm_seg_maxlen) + 2);
-#define DMS_LAUNCH(ADDv)                                                                                                                                  \
-  hipLaunchKernelGGL((spmv_dmasks_kernel<DOT, ADDv>), dim3((unsigned)nwg), dim3(PHIP_THREADS), lds, st, A->m, A->n, reinterpret_cast<const DmWords *>(A->d_tmask), A->d_widx, \
-                     reinterpret_cast<const phip_u32x16 *>(A->d_gdesc), reinterpret_cast<const int4 *>(A->d_segs), A->dm_nseg, A->dm_smin, A->dm_smax, d_x, d_yin, \
-                     d_yout, d_v, part, nty)
-        if (add) DMS_LAUNCH(true); else DMS_LAUNCH(false);
-#undef DMS_LAUNCH
-      } else if (dm_rows_env != 2 && use_g) {
+      const bool use_g = g_dm_kernel == 5 || (g_dm_kernel != 4 && (A->m >= DMG_MIN_ROWS || A->dm_npairs >= 12));
+      if (use_g) {
         nwg = (A->m + DMG_WG_ROWS - 1) / DMG_WG_ROWS;
 #define DMG_LAUNCH(ADDv)                                                                                                                                  \
   hipLaunchKernelGGL((spmv_dmaskg_kernel<DOT, ADDv>), dim3((unsigned)nwg), dim3(PHIP_THREADS), 0, st, A->m, A->n, reinterpret_cast<const DmWords *>(A->d_tmask), A->d_widx, \
@@ -2633,7 +1854,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
         static const int xcd_map = getenv("PHIP_SPMV_XCD_MAP") ? atoi(getenv("PHIP_SPMV_XCD_MAP")) : 0;
         if (add) DMG_LAUNCH(true); else DMG_LAUNCH(false);
 #undef DMG_LAUNCH
-      } else if (dm_rows_env != 2) {
+      } else {
         nwg = (A->m + PHIP_THREADS * DM4_ROWS - 1) / (PHIP_THREADS * DM4_ROWS);
         const int ug = dm_ug_env ? dm_ug_env : 1; /* 27-point 256^3: 1 / 2 / 3 / 4 groups in flight 121.6 / 126.6 / 133.0 / 147.3 us: occupancy hides the latency better */
 #define DM4_LAUNCH(ADDv, UGv)                                                                                                                             \
@@ -2642,15 +1863,6 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
         if (add) { if (ug == 2) DM4_LAUNCH(true, 2); else DM4_LAUNCH(true, 1); }
         else { if (ug == 2) DM4_LAUNCH(false, 2); else DM4_LAUNCH(false, 1); }
 #undef DM4_LAUNCH
-      } else {
-        nwg = A->sell_nslices;
-        const unsigned dgrid = (unsigned)A->sell_nslices;
-        if (dm_u_env == 8)
-          hipLaunchKernelGGL((spmv_dmask_kernel<DOT, 8>), dim3(dgrid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_rmask, A->d_dmoffs, A->d_dmvals, d_x,
-                             d_yin, d_yout, add, d_v, part, ctl, nty);
-        else
-          hipLaunchKernelGGL((spmv_dmask_kernel<DOT, 4>), dim3(dgrid), dim3(PHIP_THREADS), 0, st, A->m, A->n, A->sell_nslices, A->d_rmask, A->d_dmoffs, A->d_dmvals, d_x,
-                             d_yin, d_yout, add, d_v, part, ctl, nty);
       }
       if (DOT) { /* 16 entries per thread and round: 27-point 256^3 has 131 072 wave partials = 32 workgroups */
         const int np = nwg * (PHIP_THREADS / 64);
@@ -2667,10 +1879,8 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
       else { if (G == 2) PAIR_LAUNCH(false, 2); else PAIR_LAUNCH(false, 1); }
 #undef PAIR_LAUNCH
     }
-    else if (nt && stage) SELL_LAUNCH(true, true);
-    else if (nt) SELL_LAUNCH(true, false);
-    else if (stage) SELL_LAUNCH(false, true);
-    else SELL_LAUNCH(false, false);
+    else if (nt) SELL_LAUNCH(true);
+    else SELL_LAUNCH(false);
 #undef SELL_LAUNCH2
 #undef SELL_LAUNCH
   } else {
@@ -2682,31 +1892,7 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
     const bool       csr_nt = A->nt_user >= 0 ? A->nt_user != 0 : (csr_nt_env >= 0 ? csr_nt_env != 0 : (12 * A->nnz > PHIP_NT_MATRIX_BYTES && !A->use_cprow));
     const int32_t   *cols = A->d_col;
     const double    *xs = d_x;
-    const bool       hot = A->hot_built && A->hot_on;
-    if (A->lds_built && A->lds_on && A->nwb && (hot || A->d_lcol)) { /* hot columns from LDS, one wave per block of rows (spmv_wave_lds_kernel) */
-      if (hot) {
-        const unsigned g = (unsigned)std::min<int64_t>(((int64_t)A->n + 1023) / 1024, 16384);
-        hipLaunchKernelGGL(hot_gather_kernel, dim3(g), dim3(256), 0, st, A->n, A->d_horder, d_x, A->d_hx);
-      }
-      const int32_t K = A->lds_K;
-      const size_t  bytes = sizeof(double) * ((size_t)((K + 1) & ~1) + (size_t)LDSK_WAVES * WB_STAGE);
-      const unsigned lgrid = (unsigned)std::min<int64_t>(A->ctx->cu_count, ((int64_t)A->nwb + LDSK_WAVES - 1) / LDSK_WAVES);
-#define LDS_LAUNCH(NTv)                                                                                                                                   \
-  hipLaunchKernelGGL((spmv_wave_lds_kernel<DOT, NTv>), dim3(lgrid), dim3(LDSK_THREADS), bytes, st, A->nwb, A->d_wblkrow, A->d_wbase, A->d_wblktpr, A->d_rowptr, A->d_ridx,  \
-                     hot ? A->d_hcol : A->d_lcol, A->d_val, hot ? A->d_hx : d_x, hot ? (const int32_t *)NULL : A->d_hotlist, K, hot ? A->d_hx : d_x,       \
-                     hot ? 0 : K, d_yin, d_yout, add, A->use_cprow, d_v, A->d_wavepart)
-      if (csr_nt) LDS_LAUNCH(true); else LDS_LAUNCH(false);
-#undef LDS_LAUNCH
-      if (DOT) hipLaunchKernelGGL(dot_wave_partials_kernel, dim3(phip_grid_for((int64_t)lgrid * LDSK_WAVES, 16, PHIP_RED_GRID)), dim3(PHIP_THREADS), 0, st, A->d_wavepart,
-                                  (int)(lgrid * LDSK_WAVES), ctl);
-      PHIP_CHECK_HIP(hipGetLastError());
-      return 0;
-    }
-    if (A->rt_built && A->rt_on && A->nblocks) { /* hot columns from x', cold ones routed to their nonzeros (setup_route) */
-      int rrc = launch_route(A, d_x);
-      if (rrc) return rrc;
-      cols = A->d_rcol; xs = A->d_xe;
-    } else if (A->hot_on && A->nblocks) { /* x in the hot-column order (setup_hot) */
+    if (A->hot_on && A->nblocks) { /* x in the hot-column order (setup_hot) */
       const unsigned g = (unsigned)std::min<int64_t>(((int64_t)A->n + 1023) / 1024, 16384);
       hipLaunchKernelGGL(hot_gather_kernel, dim3(g), dim3(256), 0, st, A->n, A->d_horder, d_x, A->d_hx);
       cols = A->d_hcol; xs = A->d_hx;
@@ -2903,7 +2089,6 @@ extern "C" int phip_mat_set_threads_per_row(phip_mat A, int32_t tpr)
   PHIP_REQUIRE(tpr >= 0 && tpr <= 64 && (tpr & (tpr - 1)) == 0, PHIP_ERR_ARG_OUTOFRANGE, "threads per row must be 0 or a power of two <= 64, got %d", tpr);
   A->tpr_user = tpr;
   if (A->T) { int rc = phip_mat_set_threads_per_row(A->T, tpr); if (rc) return rc; }
-  if (A->lds_built) { int rc = upload_plan_wave(A); if (rc) return rc; }
   return upload_plan(A);
 }
 
@@ -2973,64 +2158,8 @@ extern "C" int phip_set_setup_threads(int nthreads)
 
 extern "C" int phip_set_dmask_kernel(int kind)
 {
-  PHIP_REQUIRE(kind == 0 || kind == 4 || kind == 5 || kind == 6, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_dmask_kernel: %d (0 by size, 4 bit sets per row, 5 group descriptors, 6 group descriptors with x staged in LDS)", kind);
+  PHIP_REQUIRE(kind == 0 || kind == 4 || kind == 5, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_dmask_kernel: %d (0 by size, 4 bit sets per row, 5 group descriptors)", kind);
   g_dm_kernel = kind;
-  return 0;
-}
-
-extern "C" int phip_set_default_route(int mode)
-{
-  PHIP_REQUIRE(mode >= 0 && mode <= 2, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_default_route: %d (0 never, 1 when it pays, 2 whenever there are cold nonzeros)", mode);
-  g_route_mode = mode;
-  return 0;
-}
-extern "C" int phip_set_route_hot_columns(int32_t ncols)
-{
-  PHIP_REQUIRE(ncols >= 0, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_route_hot_columns: %d", ncols);
-  g_route_hot = ncols;
-  return 0;
-}
-extern "C" int phip_mat_set_route(phip_mat A, int on)
-{
-  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_set_route: null matrix");
-  PHIP_REQUIRE(!on || A->rt_built, PHIP_ERR_SUP, "phip_mat_set_route: no routing was built for this matrix");
-  A->rt_on = on ? 1 : 0;
-  if (A->T && A->T->rt_built) A->T->rt_on = A->rt_on;
-  return 0;
-}
-extern "C" int phip_mat_route_info(phip_mat A, int *built, int *in_use, int32_t *hot_columns, int64_t *cold_nonzeros, int32_t *bins)
-{
-  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_route_info: null matrix");
-  if (built) *built = A->rt_built;
-  if (in_use) *in_use = A->rt_built && A->rt_on && !A->sell_on;
-  if (hot_columns) *hot_columns = A->rt_built ? A->rt_H : 0;
-  if (cold_nonzeros) *cold_nonzeros = A->rt_built ? A->rt_ncold : 0;
-  if (bins) *bins = A->rt_built ? A->rt_nbins : 0;
-  return 0;
-}
-
-extern "C" int phip_set_default_lds_hot(int mode)
-{
-  PHIP_REQUIRE(mode >= 0 && mode <= 2, PHIP_ERR_ARG_OUTOFRANGE, "phip_set_default_lds_hot: %d (0 never, 1 when it pays, 2 always)", mode);
-  g_lds_mode = mode;
-  return 0;
-}
-
-extern "C" int phip_mat_set_lds_hot(phip_mat A, int on)
-{
-  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_set_lds_hot: null matrix");
-  PHIP_REQUIRE(!on || A->lds_built, PHIP_ERR_SUP, "phip_mat_set_lds_hot: no LDS plan was built for this matrix");
-  A->lds_on = on ? 1 : 0;
-  return 0;
-}
-
-extern "C" int phip_mat_lds_hot_info(phip_mat A, int *built, int *in_use, int32_t *K, double *share)
-{
-  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_lds_hot_info: null matrix");
-  if (built) *built = A->lds_built;
-  if (in_use) *in_use = A->lds_built && A->lds_on && !A->sell_on && ((A->hot_built && A->hot_on) || A->d_lcol);
-  if (K) *K = A->lds_K;
-  if (share) *share = A->lds_share;
   return 0;
 }
 
@@ -3106,11 +2235,3 @@ extern "C" int phip_mat_set_nontemporal(phip_mat A, int mode)
   return 0;
 }
 
-/* tuning: gather x through LDS-staged segments in the SELL-dict kernel (see launch_spmv_t); fails when the layout has no staging plan */
-extern "C" int phip_mat_set_x_staging(phip_mat A, int on)
-{
-  PHIP_REQUIRE(A, PHIP_ERR_ARG_NULL, "phip_mat_set_x_staging: null matrix");
-  PHIP_REQUIRE(!on || (A->sell_built && A->stage_ok), PHIP_ERR_SUP, "phip_mat_set_x_staging: this matrix has no SELL-dict staging plan");
-  A->stage_user = on ? 1 : 0;
-  return 0;
-}

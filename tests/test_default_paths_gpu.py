@@ -101,7 +101,7 @@ def test_default_group_descriptor_mask_kernel(ctx):
     y0 = np.random.default_rng(9).uniform(-1.0, 1.0, m)
     dx, dy, dy0 = ctx.to_device(x), ctx.to_device(np.zeros(m)), ctx.to_device(y0)
     res = {}
-    for kind in (0, 4, 5, 6):
+    for kind in (0, 4, 5):
         ctx.check(L.phip_set_dmask_kernel(kind))
         try:
             ctx.check(L.phip_mat_mult(A, dx, dy))
@@ -114,7 +114,7 @@ def test_default_group_descriptor_mask_kernel(ctx):
             res[kind] = (mult, madd, ctx.to_host(dy, m), val[0])
         finally:
             ctx.check(L.phip_set_dmask_kernel(0))
-    for kind in (4, 5, 6):
+    for kind in (4, 5):
         for k in range(3):
             assert np.array_equal(res[kind][k], res[0][k]), (kind, k)
         assert abs(res[kind][3] - res[0][3]) <= 1e-12 * np.abs(x * res[0][0]).sum()

@@ -36,7 +36,7 @@ def mat_format(ctx, A):
     return f.value, nd.value, pad.value
 
 
-def gpu_mult(ctx, ai, aj, aa, n, x, cprow=None, y0=None, inplace=False, tpr=0, fmt=0, stage=0):
+def gpu_mult(ctx, ai, aj, aa, n, x, cprow=None, y0=None, inplace=False, tpr=0, fmt=0):
     """fmt 1: CSR row-block kernel, 2: SELL-dict kernel (returns None when the matrix is not eligible), 0: the library's choice."""
     m = len(ai) - 1
     A = ctx.mat_create(m, n, ai, aj, aa, cprow)
@@ -48,8 +48,6 @@ def gpu_mult(ctx, ai, aj, aa, n, x, cprow=None, y0=None, inplace=False, tpr=0, f
         return None
     if fmt == 1:
         ctx.check(ctx.lib.phip_mat_set_format(A, 1))
-    if stage:
-        ctx.check(ctx.lib.phip_mat_set_x_staging(A, 1))
     dx = ctx.to_device(x)
     dy = ctx.to_device(np.full(max(m, 1), 7.25))
     if y0 is None:
@@ -124,13 +122,11 @@ def test_spmv_sell_dict_layout(ctx, orc, golden_dir):
         assert f == 2 and nd <= 27 and pad >= len(aj)
         ctx.check(ctx.lib.phip_mat_destroy(A))
         np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, fmt=2), yo)
-        np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, fmt=2, stage=1), yo)  # x gathered from LDS-staged segments
         np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, tpr=1), yo)
         y0 = rng.standard_normal(n)
         zo = orc.matmultadd(ai, aj, aa, x, y0)
         np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, y0=y0, fmt=2), zo)
         np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, y0=y0, inplace=True, fmt=2), zo)
-        np.testing.assert_array_equal(gpu_mult(ctx, ai, aj, aa, n, x, y0=y0, inplace=True, fmt=2, stage=1), zo)
     # rectangular, odd row count, empty rows in the middle, x containing Inf where no entry points (padding must not touch it)
     ai = np.array([0, 2, 2, 3, 5, 5], np.int32); aj = np.array([0, 1, 2, 3, 4], np.int32); aa = np.arange(1.0, 6.0)
     x = np.array([1.0, 2.0, 3.0, 4.0, 5.0, np.inf, np.nan])
@@ -356,9 +352,8 @@ def test_value_pair_dictionary(ctx, orc):
                 assert abs(a[0] - b[0]) <= 1e-13 * np.abs(v * on[2]).sum()
             else:
                 np.testing.assert_array_equal(a, b)
-        # the mask kernels (by default size and structure decide): bit sets per row; group descriptors with transposed masks; the same
-        # with the windows of x staged in LDS
-        for kind in (4, 5, 6):
+        # the mask kernels (by default size and structure decide): bit sets per row; group descriptors with transposed masks
+        for kind in (4, 5):
             ctx.check(L.phip_set_dmask_kernel(kind))
             ctx.check(L.phip_set_default_diag_mask(2))
             try:
@@ -519,7 +514,6 @@ def test_hot_column_order(ctx, orc):
             out = {}
             for on in (1, 0):
                 ctx.check(L.phip_mat_set_hot_columns(A, on))
-                ctx.check(L.phip_mat_set_lds_hot(A, 0))        # the row-block kernel; the wave kernel has a test of its own below
                 ctx.check(L.phip_mat_mult(A, dx, dy))
                 ctx.check(L.phip_mat_multadd(A, dx, dy0, dz))
                 t = Ticket()
@@ -543,207 +537,6 @@ def test_hot_column_order(ctx, orc):
         assert info(A)[:2] == (0, 0)
         ctx.check(L.phip_mat_destroy(A))
     finally:
-        ctx.check(L.phip_set_default_hot_columns(1))
-
-
-def test_cold_column_routing(ctx, orc):
-    """Cold-column routing (setup_route: the H most used columns gathered from x' = x[order], the entries of all other columns delivered
-    to their nonzeros in CSR order by a scatter into bins and a permutation of each bin) changes where an entry of x is read from and
-    nothing else: bit-identical results for mult, multadd, the fused dot, the transpose and the compressed-row form, for several H
-    (no hot column at all, a few, most), matrices with several bins and column chunks, rows longer than a row block, and a second
-    product with another x (no entry left over from the product before).  Small matrices get no routing unless it is forced."""
-    import ctypes as C
-    from petsc_amd import generators as G
-    from petsc_amd.capi import Ticket
-    L = ctx.lib
-    rng = np.random.default_rng(99)
-
-    def info(A):
-        b, u, h, nc, nb = C.c_int(), C.c_int(), C.c_int32(), C.c_int64(), C.c_int32()
-        ctx.check(L.phip_mat_route_info(A, C.byref(b), C.byref(u), C.byref(h), C.byref(nc), C.byref(nb)))
-        return b.value, u.value, h.value, nc.value, nb.value
-
-    ai, aj, aa = G.rmat(15)
-    n = len(ai) - 1
-    A = ctx.mat_create(n, n, ai, aj, aa)
-    assert info(A)[:2] == (0, 0)                      # default rule: x far too small
-    assert L.phip_mat_set_route(A, 1) != 0
-    ctx.check(L.phip_mat_destroy(A))
-    nz_rows = np.sort(rng.choice(5000, 600, replace=False)).astype(np.int32)
-    ri = np.zeros(5001, dtype=np.int32)
-    ri[nz_rows + 1] = rng.integers(1, 60, 600)
-    ri = np.cumsum(ri).astype(np.int32)
-    rj = np.concatenate([np.sort(rng.choice(30000, ri[r + 1] - ri[r], replace=False)) for r in range(5000)]).astype(np.int32)
-    ra = rng.standard_normal(len(rj))
-    cp = (np.concatenate([[0], np.cumsum(np.diff(ri)[nz_rows])]).astype(np.int32), nz_rows)
-    li = np.array([0, 3, 20003, 20004, 20004, 60004], dtype=np.int32)
-    lj = np.concatenate([[0, 2, 5], np.arange(20000), [7], np.arange(5, 40005)]).astype(np.int32)
-    la = rng.standard_normal(len(lj))
-    cases = [(ai, aj, aa, n, None), (ri, rj, ra, 30000, cp), (li, lj, la, 40010, None)]
-    ctx.check(L.phip_set_default_route(2))
-    try:
-        for H in (0, 37, 4096):
-            ctx.check(L.phip_set_route_hot_columns(H))
-            for ci, cj, ca, ncols, cprow in cases:
-                m = len(ci) - 1
-                xs = [rng.standard_normal(ncols), rng.standard_normal(ncols)]
-                v, y0 = rng.standard_normal(m), rng.standard_normal(m)
-                A = ctx.mat_create(m, ncols, ci, cj, ca, cprow)
-                built, used, h, ncold, nbins = info(A)
-                assert (built, used, h) == (1, 1, min(H, ncols)) and 0 < ncold <= len(cj) and nbins == (ncold + 8191) // 8192
-                if ci is ai:
-                    assert nbins >= 20 and (H > 0 or ncold == len(cj))
-                ctx.check(L.phip_mat_transpose_setup(A, ci.ctypes.data_as(C.POINTER(C.c_int32)), cj.ctypes.data_as(C.POINTER(C.c_int32)),
-                                                     ca.ctypes.data_as(C.POINTER(C.c_double))))
-                dv, dy0 = ctx.to_device(v), ctx.to_device(y0)
-                dy, dz, dt, dd = (ctx.to_device(np.zeros(max(m, ncols))) for _ in range(4))
-                out = {}
-                for on in (1, 0):
-                    ctx.check(L.phip_mat_set_route(A, on))
-                    res = []
-                    for x in xs:
-                        dx = ctx.to_device(x)
-                        ctx.check(L.phip_mat_mult(A, dx, dy))
-                        ctx.check(L.phip_mat_multadd(A, dx, dy0, dz))
-                        t = Ticket()
-                        val = np.zeros(1)
-                        ctx.check(L.phip_mat_mult_dot(A, dx, dt, dv, 1, C.byref(t)))
-                        ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t), val.ctypes.data_as(C.POINTER(C.c_double))))
-                        res += [ctx.to_host(dy, m), ctx.to_host(dz, m), ctx.to_host(dt, m), val.copy()]
-                        ctx.free(dx)
-                    ctx.check(L.phip_mat_mult_transpose(A, dv, dt))
-                    res.append(ctx.to_host(dt, ncols))
-                    ctx.check(L.phip_mat_getdiagonal(A, dd))
-                    res.append(ctx.to_host(dd, m))
-                    out[on] = res
-                for a, b in zip(out[0], out[1]):
-                    np.testing.assert_array_equal(a, b)
-                assert relerr(out[1][0], orc.matmult(ci, cj, ca, xs[0])) <= 1e-12
-                for pz in (dv, dy0, dy, dz, dt, dd):
-                    ctx.free(pz)
-                ctx.check(L.phip_mat_destroy(A))
-        # the stencil layout has no use for it
-        si, sj, sa = G.laplace3d_7pt(12)
-        A = ctx.mat_create(len(si) - 1, len(si) - 1, si, sj, sa)
-        assert info(A)[:2] == (0, 0)
-        ctx.check(L.phip_mat_destroy(A))
-    finally:
-        ctx.check(L.phip_set_default_route(1))
-        ctx.check(L.phip_set_route_hot_columns(262144))
-
-
-def test_lds_hot_columns_wave_kernel(ctx, orc):
-    """spmv_wave_lds_kernel (the K most used columns of x resident in LDS, one wave per block of rows): mult, multadd (also in place), the
-    fused dot and the compressed-row form against the oracle (<= 1e-12; bit for bit with one lane per row) and against the row-block
-    kernel; with and without the hot-column order underneath; built by the default rule for an R-MAT of 2^20 nonzeros and more, never for
-    stencil or small matrices; K and the share of nonzeros served from LDS are reported."""
-    import ctypes as C
-    from petsc_amd import generators as G
-    from petsc_amd.capi import Ticket
-    L = ctx.lib
-    rng = np.random.default_rng(78)
-
-    def info(A):
-        b, u, K, sh = C.c_int(), C.c_int(), C.c_int32(), C.c_double()
-        ctx.check(L.phip_mat_lds_hot_info(A, C.byref(b), C.byref(u), C.byref(K), C.byref(sh)))
-        return b.value, u.value, K.value, sh.value
-
-    # off by default; by its rule (mode 1) R-MAT scale 17 (2.0 M nonzeros) gets the plan, scale 13 and a stencil do not
-    ai, aj, aa = G.rmat(17)
-    n = len(ai) - 1
-    A = ctx.mat_create(n, n, ai, aj, aa)
-    assert info(A)[:2] == (0, 0)
-    ctx.check(L.phip_mat_destroy(A))
-    ctx.check(L.phip_set_default_lds_hot(1))
-    A = ctx.mat_create(n, n, ai, aj, aa)
-    built, used, K, share = info(A)
-    assert (built, used) == (1, 1) and 1024 <= K <= 20000 and share >= 0.10, (built, used, K, share)
-    x, y0 = rng.standard_normal(n), rng.standard_normal(n)
-    dx, dy, dy0 = ctx.to_device(x), ctx.to_device(np.zeros(n)), ctx.to_device(y0)
-    res = {}
-    for on in (1, 0):
-        ctx.check(L.phip_mat_set_lds_hot(A, on))
-        ctx.check(L.phip_mat_mult(A, dx, dy))
-        res[on] = ctx.to_host(dy, n)
-    yo = orc.matmult(ai, aj, aa, x)
-    assert relerr(res[1], yo) <= 1e-12 and relerr(res[0], yo) <= 1e-12
-    ctx.check(L.phip_mat_set_lds_hot(A, 1))
-    ctx.check(L.phip_mat_set_threads_per_row(A, 1))     # one lane per row: the oracle's bits
-    ctx.check(L.phip_mat_mult(A, dx, dy))
-    short = np.diff(ai) <= 254                           # a row longer than a wave block is summed by the whole wave (strided + tree)
-    assert 0 < np.count_nonzero(~short) < n // 50
-    y1 = ctx.to_host(dy, n)
-    np.testing.assert_array_equal(y1[short], yo[short])
-    assert relerr(y1, yo) <= 1e-12
-    ctx.check(L.phip_mat_multadd(A, dx, dy0, dy0))      # in place, as MatMult_MPIAIJ calls it
-    z1, zo = ctx.to_host(dy0, n), orc.matmultadd(ai, aj, aa, x, y0)
-    np.testing.assert_array_equal(z1[short], zo[short])
-    assert relerr(z1, zo) <= 1e-12
-    for pz in (dx, dy, dy0):
-        ctx.free(pz)
-    ctx.check(L.phip_mat_destroy(A))
-    for gi, gj, ga in (G.rmat(13), G.laplace3d_7pt(40)):
-        A = ctx.mat_create(len(gi) - 1, len(gi) - 1, gi, gj, ga)
-        assert info(A)[:2] == (0, 0)
-        assert L.phip_mat_set_lds_hot(A, 1) != 0
-        ctx.check(L.phip_mat_destroy(A))
-    # forced on small matrices of every shape: compressed rows, a row longer than a wave block, rectangular; with the hot order under it and without
-    ctx.check(L.phip_set_default_lds_hot(2))
-    try:
-        nz_rows = np.sort(rng.choice(500, 60, replace=False)).astype(np.int32)
-        ri = np.zeros(501, dtype=np.int32)
-        ri[nz_rows + 1] = rng.integers(1, 40, 60)
-        ri = np.cumsum(ri).astype(np.int32)
-        rj = np.concatenate([np.sort(rng.choice(3000, ri[r + 1] - ri[r], replace=False)) for r in range(500)]).astype(np.int32)
-        ra = rng.standard_normal(len(rj))
-        cp = (np.concatenate([[0], np.cumsum(np.diff(ri)[nz_rows])]).astype(np.int32), nz_rows)
-        li = np.array([0, 3, 5003, 5004, 5004, 5260], dtype=np.int32)
-        lj = np.concatenate([[0, 2, 5], np.arange(5000), [7], np.arange(0, 5120, 20)]).astype(np.int32)
-        la = rng.standard_normal(len(lj))
-        si, sj, sa = G.rmat(12)
-        wide = 40000                                      # more columns than LDS holds: hot and cold gathers in one product
-        wi = np.arange(0, 301 * 50, 50).astype(np.int32)
-        wj = np.concatenate([np.sort(rng.choice(wide, 50, replace=False)) for _ in range(300)]).astype(np.int32)
-        wj[::3] = wj[::3] % 100                           # a few very hot columns (duplicates within a row are fine for the kernels)
-        wj = np.concatenate([np.sort(wj[k * 50:(k + 1) * 50]) for k in range(300)]).astype(np.int32)
-        wa = rng.standard_normal(len(wj))
-        cases = [(si, sj, sa, len(si) - 1, None), (ri, rj, ra, 3000, cp), (li, lj, la, 5200, None), (wi, wj, wa, wide, None)]
-        for hotmode in (1, 2):
-            ctx.check(L.phip_set_default_hot_columns(hotmode))
-            for ci, cj, ca, ncols, cprow in cases:
-                m = len(ci) - 1
-                x, v, y0 = rng.standard_normal(ncols), rng.standard_normal(m), rng.standard_normal(m)
-                A = ctx.mat_create(m, ncols, ci, cj, ca, cprow)
-                built, used, K, share = info(A)
-                assert (built, used) == (1, 1) and K == min(ncols, K) and 0.0 < share <= 1.0
-                dx, dv, dy0 = ctx.to_device(x), ctx.to_device(v), ctx.to_device(y0)
-                dy, dz, dt = (ctx.to_device(np.full(m, 3.5)) for _ in range(3))
-                out = {}
-                for on in (1, 0):
-                    ctx.check(L.phip_mat_set_lds_hot(A, on))
-                    for tpr in (0, 1):
-                        ctx.check(L.phip_mat_set_threads_per_row(A, tpr))
-                        ctx.check(L.phip_mat_mult(A, dx, dy))
-                        ctx.check(L.phip_mat_multadd(A, dx, dy0, dz))
-                        t = Ticket()
-                        val = np.zeros(1)
-                        ctx.check(L.phip_mat_mult_dot(A, dx, dt, dv, 1, C.byref(t)))
-                        ctx.check(L.phip_ticket_wait(ctx.h, C.byref(t), val.ctypes.data_as(C.POINTER(C.c_double))))
-                        out[on, tpr] = (ctx.to_host(dy, m), ctx.to_host(dz, m), ctx.to_host(dt, m), val.copy())
-                yo, zo = orc.matmult(ci, cj, ca, x), orc.matmultadd(ci, cj, ca, x, y0)
-                for key, (y, z, yd, val) in out.items():
-                    assert relerr(y, yo) <= 1e-12 and relerr(z, zo) <= 1e-12, key
-                    np.testing.assert_array_equal(yd, y)
-                    assert abs(val[0] - v @ y) <= 1e-12 * np.abs(v * y).sum() + 1e-300, key
-                short = np.diff(ci) <= 254
-                for on in (1, 0):                           # one lane per row: the oracle's bits, whichever kernel
-                    np.testing.assert_array_equal(out[on, 1][0][short], yo[short])
-                    np.testing.assert_array_equal(out[on, 1][1][short], zo[short])
-                for pz in (dx, dv, dy0, dy, dz, dt):
-                    ctx.free(pz)
-                ctx.check(L.phip_mat_destroy(A))
-    finally:
-        ctx.check(L.phip_set_default_lds_hot(0))
         ctx.check(L.phip_set_default_hot_columns(1))
 
 
@@ -917,7 +710,7 @@ def test_mask_kernels_repeated_diagonals(ctx, orc):
     x, y0 = G.random_vector(m), np.random.default_rng(3).standard_normal(m)
     dx, dy, dy0 = ctx.to_device(x), ctx.to_device(np.zeros(m)), ctx.to_device(y0)
     ref = orc.matmult(ai, aj, aa, x)
-    for kind in (4, 5, 6):
+    for kind in (4, 5):
         ctx.check(L.phip_set_dmask_kernel(kind))
         try:
             ctx.check(L.phip_mat_mult(A, dx, dy))
