@@ -311,7 +311,7 @@ def vec_kernels(L, ctx, tm, m, workload="", incg_batch=None, incg_xp=None):
     return out
 
 
-def rmat_leg(P, L, comm, tm, name, scale):
+def rmat_leg(P, L, comm, tm, name, scale, ranks=0):
     """single-GPU leg: SpMV of BASELINE config 5's matrix family (R-MAT, a,b,c,d = 0.57,0.19,0.19,0.05, 16 edges per row, duplicates summed) at a
     scale that generates in seconds; the product is the CSR row-block kernel's (irregular matrices have no stencil layout)"""
     from petsc_amd import generators as G
@@ -335,11 +335,84 @@ def rmat_leg(P, L, comm, tm, name, scale):
     avg, pcts = tm.kernel(lambda: L.phip_mat_mult(hA, dx, dy))
     out["roofline"] = roofline_obj(name, kernel, layout, real, alg, avg, pcts, resident_bytes=real)
     out["gathers_per_s"] = round(nz / (avg * 1e-6))
-    out["bound_note"] = ("one divergent 8-byte gather per nonzero: the texture path serves about 210 G of them a second when every line is an L2 hit, "
-                         "and from about 4 M columns on a third of them miss L2 and fill a 128-byte line each (DESIGN.md section 3)")
+    out["bound_note"] = ("one divergent 8-byte gather per nonzero: a CU serves an L1-missing gather lane in about 3 clocks (207-244 G/s chip-wide on an L2-resident "
+                         "table, scripts/micro/gather_policy.hip; 54 G/s on a 128 MiB table whatever the load's cache policy), so frac prices the kernel against a "
+                         "roofline that does not bind it: with every gather an L2 hit and the fabric traffic at the algorithmic bytes (round 3's routing experiment, "
+                         "profiles/r03_pmc_rmat22_route.json) the product of this matrix still takes 401 us (DESIGN.md section 3)")
     for o in (x, y, A):
         o.destroy()
+    if ranks:
+        out["mpiaij_%d_row_blocks" % ranks] = rank_report(P, L, ai, aj, aa, ranks)
     return out
+
+
+def rank_report(P, L, ai, aj, aa, nranks=8):
+    """What each of `nranks` MPIAIJ row blocks of this matrix holds and costs -- the part of the 8-GPU run a one-GPU box can bound: the
+    ranks run as host threads sharing the GPU (the "threads" communicator: the real partition, assembly products, ghost plan and device
+    blocks; not a performance path), and each rank in turn, alone on the GPU, times the kernel of its diagonal block (A x) and of its
+    off-diagonal block (y += B lvec).  mpiaij.c:984-998, mmaij.c:69-101."""
+    import struct
+    import threading
+    M = len(ai) - 1
+    key = struct.pack("<Q", 0x72616e6b00000000 | (os.getpid() & 0xffffffff)) + bytes(120)
+    out, err = [None] * nranks, [None] * nranks
+    turn = threading.Lock()
+    bar = threading.Barrier(nranks)
+
+    def work(r):
+        comm = None
+        try:
+            comm = P.Comm(device=0, backend="threads", id128=key, nranks=nranks, rank=r)
+            A = P.Mat.from_global_csr(comm, ai, aj, aa)
+            tmr = Timer(L, comm.ctx)
+            hA, hB = A.device_mat(0), A.device_mat(1)
+            blkA, blkB = A.block(0), A.block(1)
+            gh = A.ghosts()
+            m, ec = blkA["m"], len(gh["garray"])
+            dev = capi.Context.__new__(capi.Context)
+            dev.lib, dev.h = L, comm.ctx
+            dx, dy, dl = dev.to_device(np.linspace(-1.0, 1.0, max(m, 1))), dev.to_device(np.zeros(max(m, 1))), dev.to_device(np.linspace(-1.0, 1.0, max(ec, 1)))
+            hb, hu = C.c_int(), C.c_int()
+            L.phip_mat_hot_columns_info(hB, C.byref(hb), C.byref(hu), None, None)
+            bar.wait()
+            with turn:   # one rank at a time: the others leave the GPU alone
+                ta, _ = tmr.kernel(lambda: L.phip_mat_mult(hA, dx, dy), reps=30, warm=5)
+                tb, _ = tmr.kernel(lambda: L.phip_mat_multadd(hB, dl, dy, dy), reps=30, warm=5) if blkB["nz"] else (0.0, None)
+            out[r] = {"rank": r, "rows": m, "nnz_diag_block": blkA["nz"], "nnz_offdiag_block": blkB["nz"], "ghost_entries": ec, "entries_sent": int(len(gh["to_indices"])),
+                      "neighbours": int(len(gh["from_procs"])), "offdiag_compressed_rows": bool(blkB["cprow_use"]), "offdiag_hot_column_order": bool(hu.value),
+                      "diag_block_kernel_us": round(ta, 1), "offdiag_block_kernel_us": round(tb, 1), "exchange_bytes": 8 * (ec + int(len(gh["to_indices"])))}
+            bar.wait()
+            for p_ in (dx, dy, dl):
+                dev.free(p_)
+            A.destroy()
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+            bar.abort()
+        finally:
+            if comm is not None and err[r] is None:
+                comm.finalize()
+
+    from petsc_amd import capi
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(600)
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    if any(o is None for o in out):
+        raise RuntimeError("rank report: a rank did not finish")
+    tot = [o["diag_block_kernel_us"] + o["offdiag_block_kernel_us"] for o in out]
+    nn = [o["nnz_diag_block"] + o["nnz_offdiag_block"] for o in out]
+    return {"ranks": nranks, "per_rank": out,
+            "kernel_us_slowest_over_mean": round(max(tot) / (sum(tot) / nranks), 2), "kernel_us_slowest": round(max(tot), 1), "kernel_us_mean": round(sum(tot) / nranks, 1),
+            "nnz_slowest_over_mean": round(max(nn) / (sum(nn) / nranks), 2),
+            "offdiag_share_of_nnz": round(sum(o["nnz_offdiag_block"] for o in out) / float(sum(nn)), 3),
+            "offdiag_share_of_kernel_time": round(sum(o["offdiag_block_kernel_us"] for o in out) / sum(tot), 3),
+            "exchange_bytes_largest_rank": max(o["exchange_bytes"] for o in out),
+            "is": "the MPIAIJ partition of this matrix over %d row blocks (the %d-GPU run's), each rank's two kernels timed alone on one GPU; an upper bound of the "
+                  "%d-GPU MatMult's kernel time is kernel_us_slowest, its ghost exchange moves exchange_bytes per rank and product" % (nranks, nranks, nranks)}
 
 
 def spmv_leg(P, L, comm, tm, name, kind, n, perturb, with_cg, steps, fmt_csr_too=False, cold=False):
@@ -406,6 +479,26 @@ def spmv_leg(P, L, comm, tm, name, kind, n, perturb, with_cg, steps, fmt_csr_too
     return out
 
 
+def run_leg(P, L, comm, tm, leg, steps):
+    """one single-GPU leg by name: lap7_128 | lap7_<n>[_var] | box27_<n>[_var] | rmat_<scale>"""
+    if leg == "lap7_128":
+        o = spmv_leg(P, L, comm, tm, leg, "lap7", 128, False, True, max(steps, 20), fmt_csr_too=True, cold=True)
+        o["is"] = ("BASELINE configs[1]: SeqAIJ SpMV + CG on the 3-D 7-point Laplacian 128^3 (target: SpMV >= 70 % of HBM peak on 12 nz + 20 m + 4); "
+                   "roofline = the layout the library picks for this matrix, roofline_csr = the general CSR row-block kernel on it, which streams exactly those bytes "
+                   "(its frac is the target's figure; cold_frac the same with nothing left in the caches)")
+    elif leg.startswith("rmat_"):
+        o = rmat_leg(P, L, comm, tm, leg, int(leg.split("_")[1]), ranks=8)
+        o["is"] = "BASELINE config 5's matrix family: irregular (power-law) SpMV through the CSR row-block kernel; mpiaij_8_row_blocks = what each rank of the 8-GPU partition holds and costs"
+    else:
+        k2, n2, pv = parse_workload(leg)
+        o = spmv_leg(P, L, comm, tm, leg, k2, n2, pv, True, max(min(steps, 100), 20), fmt_csr_too=pv)
+        if pv:
+            o["is"] = ("out-of-cache, non-dictionary path -- what a MatSetValues-assembled variable-coefficient operator gets (aij.c:430-501, 1313-1320): SpMV + "
+                       "KSPCG+PCJACOBI through SELL-dict with streamed values (roofline, cg_iters_per_s) and through the general CSR row-block kernel "
+                       "(roofline_csr, cg_iters_per_s_csr) on the same matrix")
+    return o
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -415,10 +508,20 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--legs", default="auto", help="auto (N=1: lap7_128,lap7_256_var,box27_256_var,rmat_22) | none | comma-separated names (lap7_<n>, box27_<n>, rmat_<scale>)")
     ap.add_argument("--ksp", default="cg", choices=["cg", "pipecg"], help="developer switch; the judged metric is KSPCG")
+    ap.add_argument("--leg-only", default="", help="developer switch (scripts/collect_profiles.sh): run just this leg and print {\"legs\": {...}}, so that a profile holds one matrix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     a = ap.parse_args()
 
+    if a.leg_only:
+        from petsc_amd import capi, petsc as P
+        comm = P.Comm(device=0, backend="self")
+        L = capi.load()
+        tm = Timer(L, comm.ctx)
+        print(json.dumps({"legs": {a.leg_only: run_leg(P, L, comm, tm, a.leg_only, a.steps)}}), flush=True)
+        tm.close()
+        comm.finalize()
+        return
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         # a plain `python bench.py --gpus N`: this process becomes the launcher -- before it touches HIP, RCCL or torch -- of N fresh
         # ranks, one GPU each (the reference's parallel tests are launched the same way: cmake/TestRunner.cmake:5-18, `${MPIEXEC} -n N exe`)
@@ -689,21 +792,7 @@ def main():
             legs = "lap7_128,lap7_256_var,box27_256_var,rmat_22"
         out["legs"] = {}
         for leg in [s for s in legs.split(",") if s and s != "none"]:
-            if leg == "lap7_128":
-                out["legs"][leg] = spmv_leg(P, L, comm, tm, leg, "lap7", 128, False, True, max(a.steps, 20), fmt_csr_too=True, cold=True)
-                out["legs"][leg]["is"] = ("BASELINE configs[1]: SeqAIJ SpMV + CG on the 3-D 7-point Laplacian 128^3 (target: SpMV >= 70 % of HBM peak on 12 nz + 20 m + 4); "
-                                          "roofline = the layout the library picks for this matrix, roofline_csr = the general CSR row-block kernel on it, which streams exactly those bytes "
-                                          "(its frac is the target's figure; cold_frac the same with nothing left in the caches)")
-            elif leg.startswith("rmat_"):
-                out["legs"][leg] = rmat_leg(P, L, comm, tm, leg, int(leg.split("_")[1]))
-                out["legs"][leg]["is"] = "BASELINE config 5's matrix family: irregular (power-law) SpMV through the CSR row-block kernel"
-            else:
-                k2, n2, pv = parse_workload(leg)
-                out["legs"][leg] = spmv_leg(P, L, comm, tm, leg, k2, n2, pv, True, max(min(a.steps, 100), 20), fmt_csr_too=pv)
-                if pv:
-                    out["legs"][leg]["is"] = ("out-of-cache, non-dictionary path -- what a MatSetValues-assembled variable-coefficient operator gets (aij.c:430-501, 1313-1320): SpMV + "
-                                              "KSPCG+PCJACOBI through SELL-dict with streamed values (roofline, cg_iters_per_s) and through the general CSR row-block kernel "
-                                              "(roofline_csr, cg_iters_per_s_csr) on the same matrix")
+            out["legs"][leg] = run_leg(P, L, comm, tm, leg, a.steps)
         if keep_host_csr:
             out["cpu_baseline"] = cpu_baseline(ai, aj, aa, m, iter_bytes, spmv_bytes, a.cpu_seconds)
     tm.close()
