@@ -1897,9 +1897,13 @@ static int launch_spmv_t(phip_mat A, const double *d_x, const double *d_yin, dou
       hipLaunchKernelGGL(hot_gather_kernel, dim3(g), dim3(256), 0, st, A->n, A->d_horder, d_x, A->d_hx);
       cols = A->d_hcol; xs = A->d_hx;
     }
-    /* runs of 128 row blocks per XCD from 32 Ki blocks on, of 16 below: R-MAT scale 20 (10 400 blocks, the heavy rows in the first of them)
-       90.6 / 91.9 / 98.1 us with runs of 1 / 16 / 128 -- long runs put the expensive start of such a matrix on one XCD */
-    const int xlc = (grid % 8 == 0 || !DOT) ? xcd_chunk_log2(A->nblocks >= 32768 ? XCD_CHUNK_LOG2_CSR : 4) : 0; /* a strided grid keeps a workgroup on its XCD only if 8 divides it */
+    /* row blocks per XCD run: 512 for a large matrix known to be banded (it also has the SELL-dict layout): 7-point 256^3, every value
+       perturbed, 16 / 128 / 512 / 1024 blocks: 318 / 303 / 308 / 314 us with 1.02 / 1.16 / 1.09 / ~1.05 x the algorithmic bytes of fabric
+       traffic (runs shorter than the far diagonals' distance, 256 blocks here, put a block and its far neighbours on different XCDs and x
+       crosses the fabric three times; much longer runs make eight XCDs stream eight distant regions); 128 for other large matrices;
+       16 below 32 Ki blocks: R-MAT scale 20 (10 400 blocks, the heavy rows in the first of them) 90.6 / 91.9 / 98.1 us with runs of
+       1 / 16 / 128 -- long runs put the expensive start of such a matrix on one XCD */
+    const int xlc = (grid % 8 == 0 || !DOT) ? xcd_chunk_log2(A->nblocks >= 32768 ? (A->sell_built ? 9 : XCD_CHUNK_LOG2_CSR) : 4) : 0; /* a strided grid keeps a workgroup on its XCD only if 8 divides it */
     if (csr_nt)
       hipLaunchKernelGGL((spmv_rowblock_kernel<DOT, true>), dim3(grid), dim3(PHIP_THREADS), 0, st, A->nblocks, A->d_blkrec, A->d_rowptr, A->d_ridx, cols,
                          A->d_val, xs, d_yin, d_yout, add, A->use_cprow, d_v, ctl, xlc);

@@ -29,10 +29,10 @@ def main():
         x.set_array(np.linspace(-1.0, 1.0, m))
         dx, dy = x.device_ptr(), y.device_ptr()
         ref = None
-        for fmt in (1, 0):
+        for fmt in [int(v) for v in os.environ.get('FMTS', '1,0').split(',')]:
             assert L.phip_mat_set_format(hA, fmt) == 0
             kernel, layout, real, alg = B.layout_of(L, hA, m, m, nz)
-            for chunk in (1, 2, 4, 8, 16, 32, 64, 128):
+            for chunk in [int(v) for v in os.environ.get('CHUNKS', '1,2,4,8,16,32,64,128').split(',')]:
                 assert L.phip_set_xcd_chunk(chunk) == 0
                 avg, pcts = tm.kernel(lambda: L.phip_mat_mult(hA, dx, dy), reps=100, warm=10)
                 yv = y.array()
