@@ -807,35 +807,47 @@ def main():
 def self_launch(n):
     """`python bench.py --gpus N` from a plain shell: start N ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
     set, rank r on GPU r modulo the visible devices), wait for them under a time limit, forward rank 0's JSON line, return non-zero when
-    any rank failed.  The launcher itself never initialises HIP.  PHIP_BENCH_TIMEOUT (seconds, default 1500)."""
+    any rank failed.  The launcher itself never initialises HIP.  PHIP_BENCH_TIMEOUT (seconds, default 900)."""
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    limit = float(os.environ.get("PHIP_BENCH_TIMEOUT", "1500"))
+    limit = float(os.environ.get("PHIP_BENCH_TIMEOUT", "900"))
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=(r == 0)))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)  # rank 0's line; never blocks the ranks
+    reader.start()
     t0 = time.time()
     rc = 0
-    out0 = ""
-    try:
-        out0, _ = procs[0].communicate(timeout=limit)
-        for p_ in procs:
-            p_.wait(timeout=max(limit - (time.time() - t0), 10.0))
-    except subprocess.TimeoutExpired:
-        sys.stderr.write("bench: ranks still running after %.0f s, stopping them\n" % limit)
-        rc = 124
+    while True:
+        codes = [p_.poll() for p_ in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:  # a rank died: the others would wait for it in a barrier until their own time limits
+            sys.stderr.write("bench: rank %d exited with %s, stopping the other ranks\n" % bad[0])
+            rc = bad[0][1] if bad[0][1] > 0 else 1
+            break
+        if time.time() - t0 > limit:
+            sys.stderr.write("bench: ranks still running after %.0f s, stopping them\n" % limit)
+            rc = 124
+            break
+        time.sleep(0.2)
     for r, p_ in enumerate(procs):
         if p_.poll() is None:
             p_.kill()  # exactly the processes started above
             p_.wait()
-        if p_.returncode and not rc:
+        elif p_.returncode and not rc:
             sys.stderr.write("bench: rank %d exited with %s\n" % (r, p_.returncode))
             rc = p_.returncode if p_.returncode > 0 else 1
+    reader.join(10)
+    out0 = "".join(c for c in chunks if c)
     lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
     if lines and not rc:
         print(lines[-1], flush=True)
