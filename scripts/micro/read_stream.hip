@@ -1,0 +1,88 @@
+// Micro-benchmark: what does a READ-ONLY stream out of HBM reach on this part, in the shapes the SpMV kernels read their matrices in?
+//   shape 0: grid-stride, 16 bytes a lane, consecutive workgroups read consecutive 4 KiB (the vector kernels' shape)
+//   shape 1: every workgroup owns one contiguous chunk (CHUNK bytes) and walks it in 4 KiB steps, U steps requested at a time
+//            (the SELL-dict kernel's shape: a slice of 512 rows x L slots is one chunk of 4 KiB x L)
+// over 1.25 GiB and 4 GiB (the 7-point and 27-point 256^3 matrices), non-temporal loads, nothing written but one double a lane.
+// Build: hipcc --offload-arch=gfx950 -O3 scripts/micro/read_stream.hip -o scripts/micro/read_stream
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ldnt(const double2 *p)
+{
+  const f64x2 v = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p));
+  return make_double2(v.x, v.y);
+}
+#define CHECK(c) do { hipError_t e = (c); if (e != hipSuccess) { printf("%s: %s\n", #c, hipGetErrorString(e)); return 1; } } while (0)
+
+__global__ __launch_bounds__(256) void grid_stride_kernel(const double2 *__restrict__ a, size_t n16, double *__restrict__ out)
+{
+  const size_t stride = (size_t)gridDim.x * 256;
+  double       s = 0.0;
+  size_t       i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const double2 p = ldnt(a + i), q = ldnt(a + i + stride);
+    const double2 r = ldnt(a + i + 2 * stride), t = ldnt(a + i + 3 * stride);
+    s += p.x + p.y + q.x + q.y + r.x + r.y + t.x + t.y;
+  }
+  for (; i < n16; i += stride) { const double2 p = ldnt(a + i); s += p.x + p.y; }
+  if (s == 12345.678) out[0] = s;
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void chunk_kernel(const double2 *__restrict__ a, int steps, double *__restrict__ out)
+{
+  const double2 *p = a + (size_t)blockIdx.x * steps * 256 + threadIdx.x;
+  double         s = 0.0;
+  int            k = 0;
+  for (; k + U <= steps; k += U) {
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = ldnt(p + (size_t)(k + u) * 256);
+#pragma unroll
+    for (int u = 0; u < U; u++) s += v[u].x + v[u].y;
+  }
+  for (; k < steps; k++) { const double2 v = ldnt(p + (size_t)k * 256); s += v.x + v.y; }
+  if (s == 12345.678) out[0] = s;
+}
+
+int main()
+{
+  const size_t cap = (size_t)4 << 30;
+  double      *d_a, *d_out;
+  CHECK(hipMalloc((void **)&d_a, cap));
+  CHECK(hipMalloc((void **)&d_out, 4096));
+  CHECK(hipMemset(d_a, 0, cap));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+#define TIME(LABEL, BYTES, LAUNCH)                                                                                      \
+  {                                                                                                                     \
+    LAUNCH; LAUNCH;                                                                                                     \
+    CHECK(hipDeviceSynchronize());                                                                                      \
+    CHECK(hipEventRecord(e0, 0));                                                                                       \
+    for (int r = 0; r < 10; r++) { LAUNCH; }                                                                            \
+    CHECK(hipEventRecord(e1, 0));                                                                                       \
+    CHECK(hipEventSynchronize(e1));                                                                                     \
+    float ms;                                                                                                           \
+    CHECK(hipEventElapsedTime(&ms, e0, e1));                                                                            \
+    printf("{\"shape\": \"%s\", \"bytes\": %zu, \"us\": %.1f, \"GBps\": %.0f}\n", LABEL, (size_t)(BYTES), ms * 100.0,   \
+           (double)(BYTES) / (ms / 10.0 * 1e-3) / 1e9);                                                                 \
+    fflush(stdout);                                                                                                     \
+  }
+  for (size_t bytes : {(size_t)1280 << 20, (size_t)4 << 30}) {
+    const size_t n16 = bytes / 16;
+    for (int grid : {2048, 8192, 65536})
+      TIME(grid == 2048 ? "grid-stride 2048 wg" : grid == 8192 ? "grid-stride 8192 wg" : "grid-stride 65536 wg", bytes,
+           hipLaunchKernelGGL(grid_stride_kernel, dim3(grid), dim3(256), 0, 0, (const double2 *)d_a, n16, d_out));
+    for (int steps : {7, 27}) {
+      const unsigned nwg = (unsigned)(bytes / ((size_t)steps * 4096));
+      const size_t   moved = (size_t)nwg * steps * 4096;
+      char           label[96];
+      snprintf(label, sizeof label, "chunks of %d x 4 KiB, 4 at a time", steps);
+      TIME(label, moved, hipLaunchKernelGGL(chunk_kernel<4>, dim3(nwg), dim3(256), 0, 0, (const double2 *)d_a, steps, d_out));
+      snprintf(label, sizeof label, "chunks of %d x 4 KiB, 8 at a time", steps);
+      TIME(label, moved, hipLaunchKernelGGL(chunk_kernel<8>, dim3(nwg), dim3(256), 0, 0, (const double2 *)d_a, steps, d_out));
+    }
+  }
+  return 0;
+}
