@@ -785,7 +785,7 @@ __device__ __forceinline__ void dmg_step(double (&s)[4], const double (&w)[DM4_W
    the L1 holds, its hits on the windows' overlaps are what the kernel lives on), contiguous lanes with pairs of rows (91 us), entries
    4 and 5 of the window from the next lane through the lane-shift network (v_mov_b32 wave_shl:1; 93 us with a third fewer bytes
    requested), the same with 16-byte aligned loads and 252 or 248 rows a wave (106 / 112 us: 65 % more L2 misses), eight rows a
-   lane (198 us), the windows staged in LDS (spmv_dmasks_kernel below: 108 us).  The same sums in the same order as spmv_dmask4_kernel: the same bits.
+   lane (198 us), the windows staged in LDS (spmv_dmasks_kernel, deleted in round 3: 108 us).  The same sums in the same order as spmv_dmask4_kernel: the same bits.
    dmin / dmax: smallest and largest diagonal of the table: a wave all of whose windows stay inside x (all but the first and last few)
    takes the loop without range tests. */
 template <bool DOT, bool ADD>
