@@ -284,3 +284,60 @@ def test_rmat16_matload_mpiaij(orc, golden_dir, size):
         np.testing.assert_array_equal(nnz, exp["nnz_rank8"])
         print("rmat16 over 8 ranks: nnz per rank %s, imbalance %.2f; lanes-per-row histogram of rank 0's diagonal block %s"
               % (nnz, max(nnz) / (sum(nnz) / 8.0), res[0]["hist"][0]))
+
+
+def test_full_size_config5(orc, tmp_path):
+    """BASELINE config 5 at the bench leg's size (R-MAT 2^22 rows, 65 M nonzeros; 2^24 is the same code on 4 x the data and is
+    measured by scripts/bench_configs.py): the matrix written in the format of MatView_SeqAIJ_Binary (aij.c:547-582), MatLoad on 8
+    ranks (mpiaij.c:2890-3089) into MATMPIAIJHIP, MatMult_MPIAIJ against the oracle's restatement (A x, then B lvec added) and
+    MatMult_SeqAIJ on one rank; the hot-column order of the row-block layout forced on and off gives the same bits."""
+    from petsc_amd import capi, generators as G, petsc as P
+    ai, aj, aa = G.rmat(22)
+    M = len(ai) - 1
+    assert (M, len(aj)) == (1 << 22, 65243634)
+    path = str(tmp_path / "rmat22.petscbin")
+    with open(path, "wb") as f:
+        f.write(np.array([1211216, M, M, len(aj)], ">i4").tobytes())
+        f.write(np.diff(ai).astype(">i4").tobytes()); f.write(aj.astype(">i4").tobytes()); f.write(aa.astype(">f8").tobytes())
+    xg = G.random_vector(M)
+    L = capi.load()
+
+    def body(comm):
+        A = P.Mat(comm)
+        A.load(path)
+        rs, re = A.ownership_range()
+        x = P.Vec.from_array(comm, xg[rs:re], M)
+        y = x.duplicate()
+        A.mult(x, y)
+        out = {"y": y.array(), "range": (rs, re), "nnz": A.block(0)["nz"] + (A.block(1)["nz"] if comm.size > 1 else 0)}
+        for o in (x, y, A):
+            o.destroy()
+        return out
+
+    for size in (8, 1):
+        res = run_ranks(size, body)
+        y = np.concatenate([r["y"] for r in res])
+        yo = orc.operator(ai, aj, aa, size).mult(xg)
+        assert np.abs(y - yo).max() <= 1e-12 * np.abs(yo).max(), size
+        assert sum(r["nnz"] for r in res) == len(aj)
+        assert [r["range"][0] for r in res] == [k * (M // size) for k in range(size)]
+    os.remove(path)
+
+    def hot(comm):
+        outs = []
+        for mode in (0, 2):
+            assert L.phip_set_default_hot_columns(mode) == 0
+            A = P.Mat.seqaij_with_arrays(comm, M, M, ai, aj, aa)
+            x, y = A.create_vecs()
+            x.set_array(xg)
+            A.mult(x, y)
+            outs.append(y.array())
+            for o in (x, y, A):
+                o.destroy()
+        assert L.phip_set_default_hot_columns(1) == 0
+        return outs
+
+    y0, y2 = run_ranks(1, hot)[0]
+    np.testing.assert_array_equal(y0, y2)
+    assert np.abs(y0 - yo).max() <= 1e-12 * np.abs(yo).max()
+
