@@ -32,7 +32,7 @@ sys.path.insert(0, os.path.join(REF, "bin"))
 sys.path.insert(0, HERE)
 import PetscBinaryIO  # noqa: E402  (reference's reader)
 
-NAMES = ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64"]
+NAMES = ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64", "poisson2", "fem1"]
 RAW_COPIES = ["tiny", "small", "spd-real-int32-float64"]
 
 

@@ -14,7 +14,7 @@ import pytest
 
 from oracle.oracle import REFINE_ALWAYS, NORM_1, NORM_2, NORM_INFINITY, NORM_1_AND_2
 
-NAMES = ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64"]
+NAMES = ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64", "poisson2", "fem1"]
 
 
 def load(golden_dir, name):
