@@ -33,6 +33,7 @@ sys.path.insert(0, HERE)
 import PetscBinaryIO  # noqa: E402  (reference's reader)
 
 NAMES = ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64", "poisson2", "fem1"]
+SUBDIR = {"afiro": "indefinite/afiro", "golan": "indefinite/golan", "A4": "matmatmult/A4.BGriffith", "P4": "matmatmult/P4.BGriffith"}  # fixture name -> file
 RAW_COPIES = ["tiny", "small", "spd-real-int32-float64"]
 
 
@@ -41,8 +42,8 @@ from plan_numpy import ranges, split_products  # noqa: E402,F401  (numpy derivat
 
 def main():
     io = PetscBinaryIO.PetscBinaryIO(precision="double", indices="32bit", complexscalars=False)
-    for name in NAMES:
-        path = os.path.join(REF, "share/petsc/datafiles/matrices", name)
+    for name in NAMES + list(SUBDIR):
+        path = os.path.join(REF, "share/petsc/datafiles/matrices", SUBDIR.get(name, name))
         objs = io.readBinaryFile(path)
         (M, N), (ai, aj, aa) = objs[0]
         ai = np.asarray(ai, dtype=np.int32)

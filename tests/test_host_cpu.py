@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64", "poisson2", "fem1"]
+NAMES = ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64", "poisson2", "fem1", "afiro", "golan", "A4", "P4"]
 
 
 @pytest.fixture(scope="module")
@@ -47,7 +47,7 @@ def test_seq_assembly_products(comm, orc, golden_dir, name):
     use, cpi, ridx = orc.check_compressed_row(ai)
     assert blk["cprow_use"] == use
     # ADD_VALUES onto existing entries, dense block insertion
-    A.set_values([0, 0], [aj[0]], [1.5, 2.5], P.ADD_VALUES)
+    A.set_values([rows[0], rows[0]], [aj[0]], [1.5, 2.5], P.ADD_VALUES)  # rows[0]: the first row that has an entry (A4's row 0 has none)
     A.assemble()
     assert A.block(0)["a"][0] == aa[0] + 1.5 + 2.5
     A.destroy()

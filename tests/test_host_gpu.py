@@ -172,7 +172,7 @@ def test_setrandom_placearray():
         assert res[0][2] == max(2.0 * (len(a) - 1 + 100.0 * r) for r, (a, _, _) in enumerate(res))
 
 
-@pytest.mark.parametrize("name", ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64", "poisson2", "fem1"])
+@pytest.mark.parametrize("name", ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64", "poisson2", "fem1", "afiro", "golan", "A4"])
 @pytest.mark.parametrize("size", [1, 2, 3, 4])
 def test_matmult_golden(orc, golden_dir, name, size):
     from petsc_amd import petsc as P
@@ -218,7 +218,7 @@ def test_matmult_golden(orc, golden_dir, name, size):
     np.testing.assert_array_equal(d, g["diag"])
 
 
-@pytest.mark.parametrize("name", ["small", "medium", "arco1", "poisson1", "ns-real-int32-float64", "poisson2", "fem1"])
+@pytest.mark.parametrize("name", ["small", "medium", "arco1", "poisson1", "ns-real-int32-float64", "poisson2", "fem1", "golan", "A4"])
 @pytest.mark.parametrize("size", [1, 2, 3, 4])
 def test_matmulttranspose_golden(orc, golden_dir, name, size):
     """MatMultTranspose / MatMultTransposeAdd on Seq and MPI matrices (aij.c:1207-1266, mpiaij.c:1029-1056, 1102-1117), the MPI form

@@ -10,7 +10,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-NAMES = ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64", "poisson2", "fem1"]
+NAMES = ["tiny", "small", "medium", "arco1", "poisson1", "spd-real-int32-float64", "ns-real-int32-float64", "poisson2", "fem1", "afiro", "golan", "A4", "P4"]
 
 
 @pytest.fixture(scope="module")
