@@ -1002,6 +1002,40 @@ def test_full_size_config4(orc):
     assert np.abs(res["x"] - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
 
 
+@pytest.mark.parametrize("name", ["afiro", "golan"])
+@pytest.mark.parametrize("pc", ["none", "jacobi"])
+def test_ex25_indefinite_matrices(orc, golden_dir, name, pc):
+    """src/ksp/ksp/examples/tests/ex25.c: KSPCG with rtol 1e-7 on the symmetric INDEFINITE matrices afiro and golan (right-hand side and
+    exact solution come with the files).  ex25_1.out / ex25_2.out (158 / 56 iterations to convergence) predate the test of cg.c:215-219
+    and cannot come out of this source: KSPSolve_CG stops with KSP_DIVERGED_INDEFINITE_MAT (or _PC, cg.c:187-190) as soon as p'Ap changes
+    sign.  Error behaviour is part of the contract: same reason and iteration as the oracle, same residual at the stop."""
+    from petsc_amd import petsc as P
+    g = load(golden_dir, name)
+    ai, aj, aa, b = g["i"], g["j"], g["a"], g["vec0"]
+    n = len(ai) - 1
+
+    def body(comm):
+        A = P.Mat.seqaij_with_arrays(comm, n, n, ai, aj, aa)
+        bv = P.Vec.from_array(comm, b, n)
+        x = bv.duplicate()
+        ksp = P.KSP(comm, "cg", pc)
+        ksp.set_operators(A)
+        ksp.set_tolerances(rtol=1e-7)
+        ksp.set_residual_history()
+        x.set(0.0)
+        res = ksp.solve(bv, x)
+        for o in (ksp, x, bv, A):
+            o.destroy()
+        return res
+
+    res = run_ranks(1, body)[0]
+    ref = orc.operator(ai, aj, aa, 1).solve(b, "cg", pc, rtol=1e-7)
+    assert ref["reason"] in (-8, -10)  # KSP_DIVERGED_INDEFINITE_PC / _MAT (petscksp.h)
+    assert (res["reason"], res["its"]) == (ref["reason"], ref["its"])
+    k = min(len(res["history"]), len(ref["history"]))
+    assert np.abs(res["history"][:k] - ref["history"][:k]).max() <= 1e-9 * ref["history"][0]
+
+
 @pytest.mark.parametrize("size", [1, 2, 3])
 def test_byproduct_cache(orc, size):
     """VecTDot(P,W) after MatMult(A,P,W), VecNorm(Z) and VecTDot(Z,R) after VecPointwiseMult(Z,R,D) are served from by-products
