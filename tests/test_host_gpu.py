@@ -1002,6 +1002,102 @@ def test_full_size_config4(orc):
     assert np.abs(res["x"] - ref["x"]).max() <= 1e-9 * np.abs(ref["x"]).max()
 
 
+EX5_2_OUT = [["142.26", "56.7664", "28.4652", "16.0205", "6.37762", "2.18849", "0.698897", "0.1896", "0.0311023", "0.00173053", "< 1.e-11"],
+             ["171.949", "51.7756", "16.2674", "5.93715", "0.787126", "0.156071", "0.0363183", "0.005189", "0.000484311", "1.74022e-05"]]
+EX2F_1_OUT = ["1.11803", "0.591608", "0.316228", "< 1.e-11"]
+
+
+def test_ex5_2_golden_history():
+    """src/ksp/ksp/examples/tutorials/ex5.c on 2 ranks with -ksp_rtol .000001 (makefile runex5_2; n = 2 * size, u = local index + 100 *
+    rank): the second system is assembled by COLUMN blocks (ex5.c:232-241), so half of every rank's values travel through the stash;
+    both residual histories must print as tutorials/output/ex5_2.out."""
+    from petsc_amd import petsc as P
+    m, size = 3, 2
+    n = 2 * size
+
+    def body(comm):
+        rank = comm.rank
+        A = P.Mat(comm, P.PETSC_DECIDE, P.PETSC_DECIDE, m * n, m * n, "aijhip")
+        A.set_up()
+        rs, re = A.ownership_range()
+
+        def stencil(Ii, dv):
+            i, j = Ii // n, Ii % n
+            if i > 0: A.set_values([Ii], [Ii - n], [-1.0], P.ADD_VALUES)
+            if i < m - 1: A.set_values([Ii], [Ii + n], [-1.0], P.ADD_VALUES)
+            if j > 0: A.set_values([Ii], [Ii - 1], [-1.0], P.ADD_VALUES)
+            if j < n - 1: A.set_values([Ii], [Ii + 1], [-1.0], P.ADD_VALUES)
+            A.set_values([Ii], [Ii], [dv], P.ADD_VALUES)
+
+        for Ii in range(rs, re):
+            stencil(Ii, 4.0)
+        A.assemble()
+        u, b = A.create_vecs()
+        u.set_array(np.arange(re - rs, dtype=float) + 100.0 * rank)
+        x = u.duplicate()
+        ksp = P.KSP(comm, "gmres", "jacobi")
+        ksp.gmres_set_cgs_refinement(P.REFINE_ALWAYS)
+        ksp.set_tolerances(rtol=1e-6)
+        ksp.set_residual_history()
+        hists, its = [], []
+        for stage in range(2):
+            if stage:
+                A.zero_entries()
+                for i in range(m):
+                    for j in range(2 * rank, 2 * rank + 2):
+                        stencil(j + n * i, 6.0)
+                A.assemble()
+            A.mult(u, b)
+            ksp.set_operators(A)
+            res = ksp.solve(b, x)
+            hists.append([monitor_short(v) for v in res["history"]])
+            its.append(res["its"])
+        for o in (ksp, u, b, x, A):
+            o.destroy()
+        return hists, its
+
+    hists, its = run_ranks(size, body)[0]
+    assert hists == EX5_2_OUT and its == [10, 9]
+
+
+@pytest.mark.parametrize("size", [1, 2])
+def test_ex2f_golden_history(size):
+    """src/ksp/ksp/examples/tutorials/ex2f.F (the 5-point Laplacian of ex2 on a 3 x 3 grid, u = 1, b = A u, GMRES + Jacobi with
+    refine_always, default tolerances; makefile runex2f on 2 ranks): tutorials/output/ex2f_1.out, 3 iterations, error below 1e-12."""
+    from petsc_amd import petsc as P
+    m = n = 3
+
+    def body(comm):
+        A = P.Mat(comm, P.PETSC_DECIDE, P.PETSC_DECIDE, m * n, m * n, "aijhip")
+        A.set_up()
+        rs, re = A.ownership_range()
+        for II in range(rs, re):
+            i, j = II // n, II % n
+            if i > 0: A.set_values([II], [II - n], [-1.0], P.INSERT_VALUES)
+            if i < m - 1: A.set_values([II], [II + n], [-1.0], P.INSERT_VALUES)
+            if j > 0: A.set_values([II], [II - 1], [-1.0], P.INSERT_VALUES)
+            if j < n - 1: A.set_values([II], [II + 1], [-1.0], P.INSERT_VALUES)
+            A.set_values([II], [II], [4.0], P.INSERT_VALUES)
+        A.assemble()
+        u, b = A.create_vecs()
+        u.set(1.0)
+        A.mult(u, b)
+        x = u.duplicate()
+        ksp = P.KSP(comm, "gmres", "jacobi")
+        ksp.gmres_set_cgs_refinement(P.REFINE_ALWAYS)
+        ksp.set_operators(A)
+        ksp.set_residual_history()
+        res = ksp.solve(b, x)
+        res["x"] = x.array()
+        for o in (ksp, u, b, x, A):
+            o.destroy()
+        return res
+
+    res = run_ranks(size, body)
+    assert [monitor_short(v) for v in res[0]["history"]] == EX2F_1_OUT and res[0]["its"] == 3
+    assert np.linalg.norm(gather([r["x"] for r in res]) - 1.0) < 1e-12
+
+
 @pytest.mark.parametrize("name", ["afiro", "golan"])
 @pytest.mark.parametrize("pc", ["none", "jacobi"])
 def test_ex25_indefinite_matrices(orc, golden_dir, name, pc):

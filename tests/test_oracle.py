@@ -241,6 +241,31 @@ def test_gmres_jacobi_ex5_golden(orc):
         assert res["its"] == 5
 
 
+EX5_2_OUT = [["142.26", "56.7664", "28.4652", "16.0205", "6.37762", "2.18849", "0.698897", "0.1896", "0.0311023", "0.00173053", "< 1.e-11"],
+             ["171.949", "51.7756", "16.2674", "5.93715", "0.787126", "0.156071", "0.0363183", "0.005189", "0.000484311", "1.74022e-05"]]
+
+
+def test_gmres_jacobi_ex5_2_golden(orc):
+    """tutorials/output/ex5_2.out: ex5 on 2 ranks (n = 2 * size = 4, 12 unknowns, u = local index + 100 * rank), -ksp_rtol .000001."""
+    u = np.concatenate([np.arange(6.0), np.arange(6.0) + 100.0])
+    for k, dv in enumerate((4.0, 6.0)):
+        A = ex5_matrix(orc, dv, 3, 4)
+        op = orc.operator(A["i"], A["j"], A["a"], 2)
+        res = op.solve(op.mult(u), "gmres", "jacobi", rtol=1e-6, cgs_refine=REFINE_ALWAYS)
+        assert [monitor_short(v) for v in res["history"]] == EX5_2_OUT[k]
+        assert res["its"] == (10, 9)[k]
+
+
+@pytest.mark.parametrize("size", [1, 2])
+def test_gmres_jacobi_ex2f_golden(orc, size):
+    """tutorials/output/ex2f_1.out: the 3 x 3 five-point Laplacian of ex2f.F, u = 1, b = A u, GMRES + Jacobi, refine_always."""
+    A = ex5_matrix(orc, 4.0, 3, 3)
+    op = orc.operator(A["i"], A["j"], A["a"], size)
+    res = op.solve(op.mult(np.ones(9)), "gmres", "jacobi", cgs_refine=REFINE_ALWAYS)
+    assert [monitor_short(v) for v in res["history"]] == ["1.11803", "0.591608", "0.316228", "< 1.e-11"] and res["its"] == 3
+    assert np.linalg.norm(res["x"] - 1.0) < 1e-12
+
+
 def test_cg_jacobi_poisson(orc, golden_dir):
     """No reference golden exists for KSPCG+PCJACOBI; check the driver against numpy algebra."""
     g = load(golden_dir, "spd-real-int32-float64")
