@@ -77,6 +77,32 @@ def monitor_short(v):
     return "< 1.e-11"
 
 
+def ex18_vectors(n=15):
+    """the two vectors of src/vec/vec/examples/tests/ex18.c:27-32"""
+    i = np.arange(n, dtype=np.float64)
+    x = i + 1.0 / (i + .35)
+    return x, x + 1.375547826473644376
+
+
+def test_vecdot_known_answer_ex18():
+    """src/vec/vec/examples/tests/ex18.c ("Compares BLAS dots on different machines"): VecDot of two 15-entry vectors must print as
+    tests/output/ex18_1.out, 13 significant digits.  On one rank (as the reference runs it) and split over 2 and 3."""
+    from petsc_amd import petsc as P
+    xg, yg = ex18_vectors()
+
+    def body(comm):
+        rs, re = local_slice(comm, len(xg))
+        x = P.Vec.from_array(comm, xg[rs:re], len(xg))
+        y = P.Vec.from_array(comm, yg[rs:re], len(xg))
+        v = x.dot(y)
+        x.destroy(); y.destroy()
+        return v
+
+    for size in (1, 2, 3):
+        for v in run_ranks(size, body):
+            assert "Vector inner product %16.12e" % v == "Vector inner product 1.202435522115e+03"
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def test_vec_closed_forms_ex1():
     """src/vec/vec/examples/tutorials/ex1.c:71-153 (golden output ex1_1.out: every error prints 0)."""

@@ -266,6 +266,14 @@ def test_gmres_jacobi_ex2f_golden(orc, size):
     assert np.linalg.norm(res["x"] - 1.0) < 1e-12
 
 
+def test_vecdot_known_answer_ex18(orc):
+    """src/vec/vec/examples/tests/ex18.c:27-35 and tests/output/ex18_1.out: a 13-digit known answer for VecDot."""
+    i = np.arange(15, dtype=np.float64)
+    x = i + 1.0 / (i + .35)
+    y = x + 1.375547826473644376
+    assert "Vector inner product %16.12e" % orc.dot(x, y) == "Vector inner product 1.202435522115e+03"
+
+
 def test_cg_jacobi_poisson(orc, golden_dir):
     """No reference golden exists for KSPCG+PCJACOBI; check the driver against numpy algebra."""
     g = load(golden_dir, "spd-real-int32-float64")
