@@ -49,6 +49,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec; ~6.3 TB/s is what a streaming copy achieves
+READ_STREAM_CEILING_GBPS = 7100.0  # measured, profiles/r03_micro_read_stream.jsonl (7.0 - 7.17 TB/s); context for the fractions, never the peak
 REPS = 200
 
 
@@ -255,7 +256,10 @@ def roofline_obj(workload, kernel, layout, real_bytes, alg_bytes, avg_us, pcts, 
          "traffic": traffic, "traffic_source": src, "traffic_stale": stale, "bytes_per_launch": int(real_bytes), "avg_launch_us": round(avg_us, 2), "launch_us_p10_p50_p90": pcts,
          "launches_timed": REPS, "layout": layout,
          "algorithmic_bytes_per_launch": int(alg_bytes), "algorithmic_over_layout_bytes": round(alg_bytes / float(real_bytes), 3),
-         "achieved_is": "bytes the kernel moves in its device layout (x and y once each) / average launch time"}
+         "achieved_is": "bytes the kernel moves in its device layout (x and y once each) / average launch time",
+         # context, not a peak: what a bare read-only stream of 4 GiB reaches on this part in the shape these kernels read their
+         # matrices in (scripts/micro/read_stream.hip, committed result profiles/r03_micro_read_stream.jsonl); frac stays against 8 TB/s
+         "read_stream_ceiling_GBps": READ_STREAM_CEILING_GBPS}
     if alg_bytes <= 1.001 * real_bytes:
         o["streams_the_csr"] = True  # the SURVEY.md 8d figure and the real figure coincide: frac IS the north star's "% of HBM peak on 12 nz + 20 m + 4"
     if resident_bytes is not None and resident_bytes < (240 << 20):
