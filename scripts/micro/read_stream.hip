@@ -46,6 +46,33 @@ __global__ __launch_bounds__(256) void chunk_kernel(const double2 *__restrict__ 
   if (s == 12345.678) out[0] = s;
 }
 
+/* the SELL-dict kernel's two streams: per step 4 KiB of values (16 bytes a lane) and 512 bytes of codes (2 bytes a lane), either as two
+   arrays (MERGED = false: values at a, codes at c) or as one chunk of 4.5 KiB a step (MERGED = true) */
+template <int U, bool MERGED, int LDS_KB = 0>
+__global__ __launch_bounds__(256) void two_stream_kernel(const double2 *__restrict__ a, const unsigned short *__restrict__ c, int steps, double *__restrict__ out)
+{
+  /* LDS_KB > 0: that much LDS a workgroup, touched once, only to hold the occupancy down (160 KiB a CU: 32 -> 5, 48 -> 3 workgroups) */
+  __shared__ double hold[LDS_KB > 0 ? LDS_KB * 128 : 1];
+  if (LDS_KB > 0) { hold[threadIdx.x] = (double)steps; __syncthreads(); if (hold[(threadIdx.x + 1) & 255] < 0.0) out[1] = 1.0; }
+  const size_t vstep = MERGED ? 288 : 256;   /* double2 units between the values of consecutive steps */
+  const size_t cstep = MERGED ? 2304 : 256;  /* ushort units between the codes of consecutive steps */
+  const double2        *p = a + (size_t)blockIdx.x * steps * vstep + threadIdx.x;
+  const unsigned short *q = MERGED ? reinterpret_cast<const unsigned short *>(a + (size_t)blockIdx.x * steps * vstep + 256) + threadIdx.x
+                                   : c + (size_t)blockIdx.x * steps * cstep + threadIdx.x;
+  double s = 0.0;
+  int    k = 0;
+  for (; k + U <= steps; k += U) {
+    double2        v[U];
+    unsigned short w[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { v[u] = ldnt(p + (size_t)(k + u) * vstep); w[u] = __builtin_nontemporal_load(q + (size_t)(k + u) * cstep); }
+#pragma unroll
+    for (int u = 0; u < U; u++) s += v[u].x + v[u].y + (double)w[u];
+  }
+  for (; k < steps; k++) { const double2 v = ldnt(p + (size_t)k * vstep); s += v.x + v.y + (double)__builtin_nontemporal_load(q + (size_t)k * cstep); }
+  if (s == 12345.678) out[0] = s;
+}
+
 int main()
 {
   const size_t cap = (size_t)4 << 30;
@@ -82,6 +109,18 @@ int main()
       TIME(label, moved, hipLaunchKernelGGL(chunk_kernel<4>, dim3(nwg), dim3(256), 0, 0, (const double2 *)d_a, steps, d_out));
       snprintf(label, sizeof label, "chunks of %d x 4 KiB, 8 at a time", steps);
       TIME(label, moved, hipLaunchKernelGGL(chunk_kernel<8>, dim3(nwg), dim3(256), 0, 0, (const double2 *)d_a, steps, d_out));
+      /* values + codes: 4608 bytes a step; the two-array form keeps the codes in the last ninth of the buffer */
+      const unsigned nwg2 = (unsigned)(bytes / ((size_t)steps * 4608));
+      const size_t   moved2 = (size_t)nwg2 * steps * 4608;
+      const unsigned short *codes = reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(d_a) + (size_t)nwg2 * steps * 4096);
+      snprintf(label, sizeof label, "values + codes in two arrays, %d steps, 8 at a time", steps);
+      TIME(label, moved2, hipLaunchKernelGGL((two_stream_kernel<8, false>), dim3(nwg2), dim3(256), 0, 0, (const double2 *)d_a, codes, steps, d_out));
+      snprintf(label, sizeof label, "values + codes in two arrays, %d steps, 8 at a time, 5 workgroups a CU", steps);
+      TIME(label, moved2, hipLaunchKernelGGL((two_stream_kernel<8, false, 32>), dim3(nwg2), dim3(256), 0, 0, (const double2 *)d_a, codes, steps, d_out));
+      snprintf(label, sizeof label, "values + codes in two arrays, %d steps, 8 at a time, 3 workgroups a CU", steps);
+      TIME(label, moved2, hipLaunchKernelGGL((two_stream_kernel<8, false, 48>), dim3(nwg2), dim3(256), 0, 0, (const double2 *)d_a, codes, steps, d_out));
+      snprintf(label, sizeof label, "values + codes in one 4.5 KiB chunk a step, %d steps, 8 at a time", steps);
+      TIME(label, moved2, hipLaunchKernelGGL((two_stream_kernel<8, true>), dim3(nwg2), dim3(256), 0, 0, (const double2 *)d_a, codes, steps, d_out));
     }
   }
   return 0;
