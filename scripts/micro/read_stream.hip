@@ -73,6 +73,63 @@ __global__ __launch_bounds__(256) void two_stream_kernel(const double2 *__restri
   if (s == 12345.678) out[0] = s;
 }
 
+/* the chunk stream plus, per 4 KiB step, EXTRA_KB KiB of plain loads out of a 1 MiB table that stays in every L2 (every step another piece of
+   it, so the vector L1 misses): does a line that L2 serves cost the stream as much as a line from HBM? */
+template <int U, int EXTRA_KB>
+__global__ __launch_bounds__(256) void stream_plus_l2_kernel(const double2 *__restrict__ a, const double2 *__restrict__ table, int steps, double *__restrict__ out)
+{
+  const double2 *p = a + (size_t)blockIdx.x * steps * 256 + threadIdx.x;
+  double         s = 0.0;
+  int            k = 0;
+  for (; k + U <= steps; k += U) {
+    double2 v[U], e[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = ldnt(p + (size_t)(k + u) * 256);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      /* piece (workgroup * steps + step) of the table, EXTRA_KB KiB = EXTRA_KB * 64 lanes of 16 bytes; 1 MiB = 1024 pieces of 1 KiB */
+      const unsigned piece = ((unsigned)blockIdx.x * (unsigned)steps + (unsigned)(k + u)) * EXTRA_KB % (1024u - EXTRA_KB);
+      e[u] = make_double2(0.0, 0.0);
+      if (threadIdx.x < EXTRA_KB * 64) e[u] = table[(size_t)piece * 64 + threadIdx.x];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) s += v[u].x + v[u].y + e[u].x + e[u].y;
+  }
+  for (; k < steps; k++) { const double2 v = ldnt(p + (size_t)k * 256); s += v.x + v.y; }
+  if (s == 12345.678) out[0] = s;
+}
+
+/* the chunk stream plus, per 4 KiB step, G loads of 8 bytes a lane that HIT in L1 (a window of 8 KiB of the table per workgroup, read
+   over and over): the SELL-dict kernel's mix of requests -- one 16-byte stream load and two 8-byte gathers per step and wave -- without
+   its arithmetic.  Does the address path's time for requests that hit slow the stream down? */
+template <int U, int G>
+__global__ __launch_bounds__(256) void stream_plus_l1_kernel(const double2 *__restrict__ a, const double *__restrict__ table, int steps, double *__restrict__ out)
+{
+  const double2 *p = a + (size_t)blockIdx.x * steps * 256 + threadIdx.x;
+  const double  *w = table + (size_t)(blockIdx.x & 127) * 1024 + (threadIdx.x & 63); /* 8 KiB window of this workgroup (1 MiB table) */
+  double         s = 0.0;
+  int            k = 0;
+  for (; k + U <= steps; k += U) {
+    double2 v[U];
+    double  e[U][G > 0 ? G : 1];
+    asm volatile("" : "+v"(w)); /* the window loads stay in the loop */
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = ldnt(p + (size_t)(k + u) * 256);
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int g = 0; g < G; g++) e[u][g] = w[(((k + u) * G + g) & 7) * 64 + (threadIdx.x >> 6) * 128]; /* within the 1024 doubles of the window */
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      s += v[u].x + v[u].y;
+#pragma unroll
+      for (int g = 0; g < G; g++) s += e[u][g];
+    }
+  }
+  for (; k < steps; k++) { const double2 v = ldnt(p + (size_t)k * 256); s += v.x + v.y; }
+  if (s == 12345.678) out[0] = s;
+}
+
 int main()
 {
   const size_t cap = (size_t)4 << 30;
@@ -109,6 +166,25 @@ int main()
       TIME(label, moved, hipLaunchKernelGGL(chunk_kernel<4>, dim3(nwg), dim3(256), 0, 0, (const double2 *)d_a, steps, d_out));
       snprintf(label, sizeof label, "chunks of %d x 4 KiB, 8 at a time", steps);
       TIME(label, moved, hipLaunchKernelGGL(chunk_kernel<8>, dim3(nwg), dim3(256), 0, 0, (const double2 *)d_a, steps, d_out));
+      /* the table: the last 1 MiB of the buffer (the stream stays in front of it) */
+      {
+        const unsigned  nwg3 = (unsigned)((bytes - ((size_t)1 << 20)) / ((size_t)steps * 4096));
+        const size_t    moved3 = (size_t)nwg3 * steps * 4096;
+        const double2  *table = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(d_a) + bytes - ((size_t)1 << 20));
+        snprintf(label, sizeof label, "chunks of %d x 4 KiB, 8 at a time + 1 KiB a step out of L2 (rate on the stream bytes)", steps);
+        TIME(label, moved3, hipLaunchKernelGGL((stream_plus_l2_kernel<8, 1>), dim3(nwg3), dim3(256), 0, 0, (const double2 *)d_a, table, steps, d_out));
+        snprintf(label, sizeof label, "chunks of %d x 4 KiB, 8 at a time + 2 KiB a step out of L2 (rate on the stream bytes)", steps);
+        TIME(label, moved3, hipLaunchKernelGGL((stream_plus_l2_kernel<8, 2>), dim3(nwg3), dim3(256), 0, 0, (const double2 *)d_a, table, steps, d_out));
+      }
+      {
+        const unsigned nwg3 = (unsigned)((bytes - ((size_t)1 << 20)) / ((size_t)steps * 4096));
+        const size_t   moved3 = (size_t)nwg3 * steps * 4096;
+        const double  *table = reinterpret_cast<const double *>(reinterpret_cast<const char *>(d_a) + bytes - ((size_t)1 << 20));
+        snprintf(label, sizeof label, "chunks of %d x 4 KiB, 8 at a time + 2 L1-hitting 8-byte loads a step and wave", steps);
+        TIME(label, moved3, hipLaunchKernelGGL((stream_plus_l1_kernel<8, 2>), dim3(nwg3), dim3(256), 0, 0, (const double2 *)d_a, table, steps, d_out));
+        snprintf(label, sizeof label, "chunks of %d x 4 KiB, 8 at a time + 4 L1-hitting 8-byte loads a step and wave", steps);
+        TIME(label, moved3, hipLaunchKernelGGL((stream_plus_l1_kernel<8, 4>), dim3(nwg3), dim3(256), 0, 0, (const double2 *)d_a, table, steps, d_out));
+      }
       /* values + codes: 4608 bytes a step; the two-array form keeps the codes in the last ninth of the buffer */
       const unsigned nwg2 = (unsigned)(bytes / ((size_t)steps * 4608));
       const size_t   moved2 = (size_t)nwg2 * steps * 4608;
